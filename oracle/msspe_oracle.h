@@ -1,0 +1,184 @@
+/*
+ * msspe_oracle.h -- CPU oracle for the od-msspe hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (open-msspe-design_amd/) never links, imports or executes anything in oracle/.
+ *
+ * What it restates (file:line relative to /root/reference/):
+ *   stage A  od-msspe/src/main.rs:148-406      k-mer candidates (bit-exact)
+ *   stage B  od-msspe/src/primer.rs:125-166    primer3_core call site; arithmetic = Primer3 2.6.1
+ *            oligotm() + thal() ANY / END1 / HAIRPIN (libprimer3 oligo_compl_thermod, oligo_hairpin)
+ *   stage C  od-msspe/src/delta_g.rs:61-153    ntthal call site; arithmetic = Primer3 2.6.1 thal() ANY
+ *   glue     od-msspe/src/main.rs:408-516, 739-825
+ *
+ * Primer3 2.6.1 is a third-party dependency that is NOT in the reference tree (only Mach-O arm64
+ * binaries, od-msspe/bin/).  Its published algorithm (src/thal.c, src/oligotm.c) is restated here
+ * and pinned by the reference's own golden vectors (tests/golden/).
+ * Pinned: oligotm Tm/GC (1 vector), thal ANY dS/dH/dG/t + alignment (5 vectors), stage A unit tests.
+ * PARITY UNPINNED (no reference vector exists): thal END1, thal HAIRPIN beyond the value 0.00,
+ * std-dev divisor, find_candidates_kmers as a whole, vertex cover, CSV text.
+ */
+#ifndef MSSPE_ORACLE_H
+#define MSSPE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_OLIGO 64      /* longest oligo the oracle DP tables are sized for */
+#define ORC_MAX_TLOOP 256
+
+/* ------------------------------------------------------------------------------------------
+ * Thermodynamic tables (Primer3 parameter files: od-msspe/primer3_config/ *.ds, *.dh)
+ * Base codes: A=0 C=1 G=2 T=3 N=4.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    unsigned char key[6];
+    double value;
+} orc_tloop;
+
+typedef struct {
+    double stackS[5][5][5][5], stackH[5][5][5][5];       /* stack.ds/.dh    */
+    double mmS[5][5][5][5], mmH[5][5][5][5];             /* stackmm.ds/.dh  */
+    double tstackS[5][5][5][5], tstackH[5][5][5][5];     /* tstack_tm_inf.ds + tstack.dh */
+    double tstack2S[5][5][5][5], tstack2H[5][5][5][5];   /* tstack2.ds/.dh  */
+    double d3S[5][5][5], d3H[5][5][5];                   /* dangle 3' block : [X][Y][Z] */
+    double d5S[5][5][5], d5H[5][5][5];                   /* dangle 5' block : [Z][X][Y] */
+    double interiorS[30], interiorH[30];
+    double bulgeS[30], bulgeH[30];
+    double hairpinS[30], hairpinH[30];
+    int n_tri_s, n_tri_h, n_tet_s, n_tet_h;
+    orc_tloop triS[ORC_MAX_TLOOP], triH[ORC_MAX_TLOOP];
+    orc_tloop tetS[ORC_MAX_TLOOP], tetH[ORC_MAX_TLOOP];
+} orc_tables;
+
+/* Load from a Primer3-format directory (ntthal's -path).  0 = ok. */
+int orc_tables_load_dir(const char *dir, orc_tables *t);
+/* Load from the consolidated bundle written by tools/make_param_bundle.py.  0 = ok. */
+int orc_tables_load_bundle(const char *file, orc_tables *t);
+orc_tables *orc_tables_new(void);
+void orc_tables_free(orc_tables *t);
+
+/* ------------------------------------------------------------------------------------------
+ * thal(): nearest-neighbour thermodynamic alignment (Primer3 2.6.1 src/thal.c, restated)
+ * ---------------------------------------------------------------------------------------- */
+enum { ORC_THAL_ANY = 1, ORC_THAL_END1 = 2, ORC_THAL_END2 = 3, ORC_THAL_HAIRPIN = 4 };
+
+typedef struct {
+    double mv;        /* monovalent cations, mM */
+    double dv;        /* divalent cations, mM   */
+    double dntp;      /* dNTP, mM               */
+    double dna_conc;  /* oligo, nM              */
+    double temp_k;    /* temperature the dG is reported at, Kelvin (ntthal: -t + 273.15) */
+    int max_loop;     /* 30 */
+} orc_thal_args;
+
+typedef struct {
+    int no_structure;     /* 1: thal found no duplex/hairpin (ntthal prints nothing; temp = 0) */
+    double dS;            /* salt-corrected entropy as ntthal prints it (before %g)  */
+    double dH;
+    double dG;            /* dH - temp_k * dS                                         */
+    double t;             /* melting temperature, Celsius                             */
+    double dS_raw;        /* before the N*salt term                                   */
+    int n_pairs;          /* base pairs on the traced structure                       */
+    int end1, end2;       /* best terminal cell (1-based; end2 counts the reversed oligo 2) */
+    int ps1[ORC_MAX_OLIGO];   /* dimer: ps1[i-1] = j partner (0 = unpaired)           */
+    int ps2[ORC_MAX_OLIGO];
+    int bp[ORC_MAX_OLIGO];    /* hairpin: bp[i-1] = partner                           */
+    /* instrumentation (SURVEY.md 8d asks for a measured op count) */
+    long n_cells;         /* complementary (finite) cells visited by the fill         */
+    long n_loop_evals;    /* bulge/interior candidates evaluated in the fill          */
+    long n_end_evals;     /* LSH/RSH evaluations                                      */
+    long n_f64_ops;       /* double add/sub/mul/div/compare executed, fill+pick+traceback */
+} orc_thal_result;
+
+void orc_thal_default_args(orc_thal_args *a);  /* ntthal/od-msspe defaults: 50/3/0/250, 25 C */
+void orc_p3_default_args(orc_thal_args *a);    /* primer3_core defaults: 50/1.5/0.6/50, 37 C */
+
+/* oligo1, oligo2: 5'->3' ASCII (ACGT, anything else = N).  mode = ORC_THAL_*.  0 = ok. */
+int orc_thal(const orc_tables *t, const char *oligo1, const char *oligo2, int mode,
+             const orc_thal_args *a, orc_thal_result *r);
+
+/* Dump of the dimer DP planes for debugging / checkpoints (row-major (len1 x len2), 1-based
+ * cell (i,j) at [(i-1)*len2 + (j-1)]).  Buffers must hold len1*len2 doubles. */
+int orc_thal_dimer_planes(const orc_tables *t, const char *oligo1, const char *oligo2,
+                          const orc_thal_args *a, double *S, double *H);
+
+/* ------------------------------------------------------------------------------------------
+ * oligotm(): SantaLucia-1998 NN Tm with SantaLucia salt correction (Primer3 2.6.1 oligotm.c)
+ * ---------------------------------------------------------------------------------------- */
+double orc_oligotm(const char *oligo, double dna_conc, double mv, double dv, double dntp);
+double orc_gc_percent(const char *oligo);
+
+/* primer3_core `check_primers` view of one oligo (od-msspe/src/primer.rs:143-166):
+ * values as primer3_core computes them (f64) and as od-msspe reads them back (text -> f32). */
+typedef struct {
+    double tm, gc, self_any_th, self_end_th, hairpin_th;           /* raw f64           */
+    float tm_f32, gc_f32, self_any_f32, self_end_f32, hairpin_f32; /* %.3f/%.2f -> f32  */
+} orc_primer_info;
+int orc_check_primer(const orc_tables *t, const char *oligo, orc_primer_info *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Text rounding at the process boundary
+ * ---------------------------------------------------------------------------------------- */
+float orc_round_g_f32(double x);       /* printf("%g") -> parse::<f32>()  (delta_g.rs:33-36) */
+float orc_round_fixed_f32(double x, int decimals);   /* "%.3f"/"%.2f" -> f32 (primer.rs:94-106) */
+/* ntthal-pipeline decision for one ordered pair: 1 = conflict edge (dG < threshold). */
+int orc_pair_conflict(const orc_tables *t, const char *a, const char *b,
+                      const orc_thal_args *args, float threshold, double *dg_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage A: k-mer candidate generation (od-msspe/src/main.rs:148-406), bit-exact
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int segment_size;   /* --window-size          500 */
+    int overlap_size;   /* --overlap-size (stride) 250 */
+    int window_size;    /* --search-windows-size   50 */
+    int kmer_size;      /* --kmer-size             13 */
+} orc_partition_opt;
+
+void orc_reverse_complement(const char *seq, size_t n, char *out);   /* main.rs:148-161 */
+/* find_kmers (main.rs:163-171): writes up to cap unique valid k-mers (k chars each, no NUL) into
+ * out (cap*k bytes) in positional order; returns the count. */
+int orc_find_kmers(const char *seq, size_t n, int k, char *out, int cap);
+/* partitioning_sequence (main.rs:173-181): number of partitions; offsets are j*stride. */
+int orc_partition_count(size_t len, int size, int stride);
+
+typedef struct orc_segments orc_segments;   /* SegmentManager (main.rs:82-91,196-235) */
+/* seqs: n_seq pointers to upper-cased, U->T sequences with lengths lens[]. NULL on bad options. */
+orc_segments *orc_segments_build(const char *const *seqs, const size_t *lens, int n_seq,
+                                 const orc_partition_opt *opt);
+void orc_segments_free(orc_segments *m);
+int orc_segments_count(const orc_segments *m);
+int orc_segment_partition_no(const orc_segments *m, int seg);
+int orc_segment_seq_index(const orc_segments *m, int seg);
+/* k-mers of one segment window (dir 0 = head as-is, 1 = tail reverse-complemented). */
+int orc_segment_kmer_count(const orc_segments *m, int seg, int dir);
+const char *orc_segment_kmer(const orc_segments *m, int seg, int dir, int idx); /* k chars */
+/* make_kmer_segments_windows_mapping (main.rs:237-255): number of distinct (word,dir) keys and
+ * posting-list length of one key. */
+int orc_mapping_key_count(const orc_segments *m);
+int orc_mapping_postings(const orc_segments *m, const char *word, int dir);
+
+typedef struct {
+    char word[ORC_MAX_OLIGO];  /* NUL-terminated */
+    int frequency;
+} orc_candidate;
+/* find_candidates_kmers (main.rs:331-406).  Returns number of winners written (<= cap). */
+int orc_find_candidates(const orc_segments *m, int direction, int max_iterations,
+                        int max_mismatch_segments, orc_candidate *out, int cap);
+/* find_most_freq_kmer on the initial state (main.rs:285-329), for the reference's unit test. */
+int orc_find_most_freq_kmer(const orc_segments *m, int direction, orc_candidate *out);
+
+/* is_run (main.rs:478-490) */
+int orc_is_run(const char *kmer);
+/* get_tm_stat (main.rs:462-467): f32 mean and std-dev (sample_divisor: 1 = n-1, 0 = n). */
+void orc_tm_stat(const float *tm, int n, int sample_divisor, float *mean, float *std);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
