@@ -1,0 +1,164 @@
+/*
+ * msspe_hip.h -- C ABI of the MI355X primer-screening engine (libmsspe_hip.so).
+ *
+ * Drop-in boundary for od-msspe's hot path.  The reference has no library API: it reaches its
+ * thermodynamic arithmetic through two child processes chosen by --ntthal / --primer3
+ * (/root/reference/od-msspe/src/config.rs:142-147, :179-202).  Every entry point below replaces
+ * one of those process boundaries or one in-process stage-A function, and cites it.
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add to od-msspe.
+ *
+ * Conventions:
+ *   - every call returns an int status (MSSPE_OK = 0); msspe_last_error(ctx) gives the text;
+ *   - plain pointers and sizes only, caller owns every buffer, no exceptions cross the boundary;
+ *   - one context per host thread per device; calls on different contexts are concurrent-safe;
+ *   - `_dev` entry points take DEVICE pointers and enqueue on the context's HIP stream without
+ *     synchronising (graph-capturable); the others take HOST pointers, copy, run and synchronise;
+ *   - there is NO CPU fallback: without a usable gfx950 device msspe_create() fails.
+ *
+ * Oligo encoding on the device: one uint64 per oligo, base p (0-based from the 5' end) in bits
+ * [2p, 2p+1], A=0 C=1 G=2 T=3, k <= 32.  Oligos must be pure ACGT (stage A only emits such words,
+ * od-msspe/src/main.rs:167).
+ */
+#ifndef MSSPE_HIP_H
+#define MSSPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msspe_ctx msspe_ctx;
+
+enum msspe_status {
+    MSSPE_OK = 0,
+    MSSPE_ERR_ARG = 1,      /* NULL pointer, bad range, non-ACGT oligo ...            */
+    MSSPE_ERR_K = 2,        /* unsupported oligo length                               */
+    MSSPE_ERR_TABLES = 3,   /* thermodynamic parameter files missing / malformed      */
+    MSSPE_ERR_DEVICE = 4,   /* HIP error (no device, launch failure, out of memory)   */
+    MSSPE_ERR_CAPACITY = 5, /* caller-supplied output capacity exceeded               */
+    MSSPE_ERR_NOMEM = 6
+};
+
+/* Chemistry handed to ntthal by od-msspe/src/delta_g.rs:93-110 (-mv -dv -n -d -t, all "{:.2}"
+ * strings of f32) and defaults of od-msspe/src/constants.rs:7-15. */
+typedef struct {
+    double mv;        /* monovalent cations, mM          (--mv-conc,  50)   */
+    double dv;        /* divalent cations, mM            (--dv-conc,  3)    */
+    double dntp;      /* dNTP, mM                        (--dntp-conc, 0)   */
+    double dna_conc;  /* oligo concentration, nM         (--dna-conc, 250)  */
+    double temp_c;    /* temperature dG is reported at   (--annealing-temp, 25) */
+    int max_loop;     /* ntthal -maxloop, 30                                 */
+} msspe_chem;
+
+void msspe_chem_ntthal_defaults(msspe_chem *c);   /* 50 / 3 / 0 / 250 nM / 25 C  */
+void msspe_chem_primer3_defaults(msspe_chem *c);  /* 50 / 1.5 / 0.6 / 50 nM / 37 C: what
+                                                     primer3_core uses for od-msspe's records
+                                                     (od-msspe/src/primer.rs:125-140)        */
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* device: HIP device ordinal.  params_path: a Primer3-format directory (what ntthal gets via
+ * `-path`, od-msspe/src/delta_g.rs:90,107-108), or a consolidated bundle file, or NULL for the
+ * bundle shipped next to the library. */
+int msspe_create(int device, const char *params_path, msspe_ctx **out);
+void msspe_destroy(msspe_ctx *ctx);
+const char *msspe_last_error(const msspe_ctx *ctx);
+const char *msspe_version(void);
+/* Use the caller's hipStream_t (e.g. PyTorch's current stream) for every later _dev call.
+ * NULL = the context's own stream. */
+int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
+int msspe_synchronize(msspe_ctx *ctx);
+
+/* ---- packing ------------------------------------------------------------------------------ */
+
+/* ASCII (n oligos x k chars, no separators) -> packed uint64.  Host-side helper. */
+int msspe_pack_oligos(const char *ascii, int n, int k, uint64_t *packed_out);
+void msspe_unpack_oligo(uint64_t packed, int k, char *ascii_out /* k+1 bytes */);
+
+/* ---- stage C: all-pairs cross-dimer (replaces run_ntthal, od-msspe/src/delta_g.rs:83-153) - */
+
+/*
+ * Evaluates thal ANY (Primer3 2.6.1, what `ntthal -a ANY` computes per input line) for every
+ * ORDERED pair (a = pool[i], b = pool[j]), i in [row0,row1), j in [col0,col1), self pairs
+ * included (od-msspe/src/delta_g.rs:64-78), and applies the reference's decision
+ * "%g-rounded dG parsed as f32 < threshold" (od-msspe/src/delta_g.rs:33-36).
+ *
+ * Outputs (each optional, device pointers):
+ *   row_conflicts  uint32[n]            += number of conflicting columns for each row i
+ *   bitmap         uint64[(row1-row0) * words], words = ceil((col1-col0)/64): bit (j-col0) of
+ *                  row (i-row0) set iff (i,j) conflicts; rows are written whole (no atomics)
+ *   dg             double[(row1-row0)*(col1-col0)] raw dG in cal/mol before %g rounding;
+ *                  +inf where thal finds no structure (ntthal prints nothing for such a pair;
+ *                  this engine defines "no edge")
+ *   tm             double[...] melting temperature t (Celsius), 0 where no structure
+ */
+int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
+                          const msspe_chem *chem, float dg_threshold,
+                          int row0, int row1, int col0, int col1,
+                          uint32_t *d_row_conflicts, uint64_t *d_bitmap, double *d_dg,
+                          double *d_tm);
+
+/* Host-buffer convenience: packs, uploads, runs the full n x n matrix, downloads. */
+int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
+                      const msspe_chem *chem, float dg_threshold,
+                      uint32_t *row_conflicts, uint64_t *bitmap, double *dg, double *tm);
+
+/* Number of pairs the last cross-dimer call routed to the generic (slow) kernel because their
+ * DP did not fit the fast kernel's register-resident table. */
+int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
+
+/* ---- stage B: per-oligo statistics (replaces check_primers -> primer3_core,
+ *      od-msspe/src/primer.rs:143-166) ---------------------------------------------------- */
+
+/*
+ * For each oligo: Tm (oligotm, SantaLucia), GC %, and max(0, t) of thal ANY / END1 of the oligo
+ * against itself and of thal HAIRPIN -- PRIMER_LEFT_0_{TM,GC_PERCENT,SELF_ANY_TH,SELF_END_TH,
+ * HAIRPIN_TH} (od-msspe/src/primer.rs:79-111).  Raw doubles; the text rounding primer3_core /
+ * od-msspe apply (%.3f / %.2f -> f32) is msspe_round_fixed_f32().
+ */
+int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
+                          const msspe_chem *chem, double *d_tm, double *d_gc,
+                          double *d_self_any, double *d_self_end, double *d_hairpin);
+int msspe_oligo_stats(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
+                      const msspe_chem *chem, double *tm, double *gc, double *self_any,
+                      double *self_end, double *hairpin);
+
+/* ---- stage A: k-mer candidates (replaces get_segment_manager + find_candidates_kmers,
+ *      od-msspe/src/main.rs:196-235, :331-406) -------------------------------------------- */
+
+typedef struct {
+    int segment_size;          /* --window-size           500 */
+    int overlap_size;          /* --overlap-size          250 */
+    int search_window_size;    /* --search-windows-size    50 */
+    int kmer_size;             /* --kmer-size              13 */
+    int max_iterations;        /* --max-iterations       1000 */
+    int max_mismatch_segments; /* --max-mismatch-segments (auto rule is the caller's) */
+} msspe_kmer_opt;
+
+/*
+ * seqs: n_seq aligned sequences of equal length seq_len, row-major bytes, already upper-cased
+ * with U->T (od-msspe/src/main.rs:115-118).  direction 0 = head windows as-is, 1 = tail windows
+ * reverse-complemented.  Winners are written in selection order: words as packed uint64 and
+ * their frequency.  *n_out = number of winners (<= capacity, else MSSPE_ERR_CAPACITY).
+ */
+int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
+                          const msspe_kmer_opt *opt, int direction,
+                          uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out);
+int msspe_kmer_candidates_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, size_t seq_len,
+                              const msspe_kmer_opt *opt, int direction,
+                              uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out);
+
+/* ---- text rounding at the reference's process boundary ----------- */
+
+float msspe_round_g_f32(double x);                  /* "%g"   -> f32 (od-msspe/src/delta_g.rs:33-35) */
+float msspe_round_fixed_f32(double x, int decimals);/* "%.Nf" -> f32 (od-msspe/src/primer.rs:94-106) */
+/* Largest double X such that msspe_round_g_f32(x) < threshold  <=>  x <= X (the decision cut the
+ * kernels compare against; exact by construction, found by bisection over doubles). */
+double msspe_g_cut(float threshold);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# Builds libmsspe_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# -ffp-contract=off: every double expression keeps Primer3's operation order (no FMA fusion).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+cd "$here/csrc"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math
+       -Wall -Wno-unused-function)
+mkdir -p "$here/build"
+objs=()
+for src in nn_params.cpp capi.cpp kernels_generic.hip thal_pairs.hip kmer_stage.hip; do
+  obj="$here/build/${src%.*}.o"
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || -n "$(find . -name '*.hpp' -newer "$obj" -print -quit)" \
+        || ../../include/msspe_hip.h -nt "$obj" ]]; then
+    echo "hipcc $src"
+    "$HIPCC" "${FLAGS[@]}" -x hip -c "$src" -o "$obj" ${EXTRA_HIPCC_FLAGS:-}
+  fi
+  objs+=("$obj")
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libmsspe_hip.so" "${objs[@]}" -ldl
+echo "built $here/libmsspe_hip.so"

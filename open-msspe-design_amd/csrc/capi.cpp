@@ -1,0 +1,579 @@
+// capi.cpp -- extern "C" boundary of libmsspe_hip.so (declared in include/msspe_hip.h).
+//
+// Each entry point replaces one process boundary or stage-A function of the reference:
+//   msspe_cross_dimer*     run_ntthal            /root/reference/od-msspe/src/delta_g.rs:83-153
+//   msspe_oligo_stats*     check_primers         /root/reference/od-msspe/src/primer.rs:143-166
+//   msspe_kmer_candidates* get_segment_manager + find_candidates_kmers  src/main.rs:196-235,331-406
+// There is no CPU fallback: every compute entry point needs a gfx950 device.
+#include "../../include/msspe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "kmer_stage.hpp"
+#include "nn_params.hpp"
+
+using namespace msspe;
+
+namespace {
+
+struct ChemEntry {
+    msspe_chem chem;
+    float threshold;
+    ThalConsts c[2];
+    PairTables *d_pt = nullptr;   // 2 entries: ordinary, both self-complementary
+};
+
+constexpr long kChunkPairs = 1L << 24;       // pairs per fast launch == overflow-list capacity
+constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
+
+}  // namespace
+
+struct msspe_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    NNTables host_tb;
+    NNTables *d_tb = nullptr;
+    std::vector<ChemEntry> chem_cache;
+    double *wsS = nullptr, *wsH = nullptr;
+    size_t ws_cells = 0;
+    uint2 *ovf_list = nullptr;
+    uint32_t *ovf_count = nullptr;     // [0] running counter, [1] accumulated total
+    uint64_t *d_ovf_total = nullptr;
+    std::string err;
+    KmerStage kmer;
+};
+
+namespace {
+
+int fail(msspe_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int hip_fail(msspe_ctx *ctx, hipError_t e, const char *what)
+{
+    return fail(ctx, MSSPE_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                              \
+    do {                                                                \
+        hipError_t e__ = (expr);                                        \
+        if (e__ != hipSuccess) return hip_fail((ctx), e__, #expr);      \
+    } while (0)
+
+std::string default_bundle_path()
+{
+    Dl_info info;
+    if (dladdr((void *)&msspe_version, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t slash = p.find_last_of('/');
+        p = slash == std::string::npos ? std::string(".") : p.substr(0, slash);
+        return p + "/data/nn_params.bundle";
+    }
+    return "data/nn_params.bundle";
+}
+
+bool same_chem(const msspe_chem &a, const msspe_chem &b)
+{
+    return a.mv == b.mv && a.dv == b.dv && a.dntp == b.dntp && a.dna_conc == b.dna_conc &&
+           a.temp_c == b.temp_c && a.max_loop == b.max_loop;
+}
+
+int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntry **out)
+{
+    for (auto &e : ctx->chem_cache)
+        if (same_chem(e.chem, chem) && (e.threshold == threshold ||
+                                        (std::isnan(e.threshold) && std::isnan(threshold)))) {
+            *out = &e;
+            return MSSPE_OK;
+        }
+    if (!(chem.dna_conc > 0) || chem.max_loop < 0 || chem.max_loop > 30)
+        return fail(ctx, MSSPE_ERR_ARG, "chemistry: dna_conc must be > 0 and 0 <= max_loop <= 30");
+    ChemEntry e;
+    e.chem = chem;
+    e.threshold = threshold;
+    PairTables host_pt[2];
+    for (int sym = 0; sym < 2; ++sym) {
+        e.c[sym] = make_dimer_consts(chem.mv, chem.dv, chem.dntp, chem.dna_conc, chem.temp_c,
+                                     chem.max_loop, sym == 1, threshold);
+        std::string err;
+        if (!build_pair_tables(ctx->host_tb, e.c[sym], host_pt[sym], err))
+            return fail(ctx, MSSPE_ERR_TABLES, err);
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&e.d_pt, sizeof host_pt));
+    HIP_TRY(ctx, hipMemcpy(e.d_pt, host_pt, sizeof host_pt, hipMemcpyHostToDevice));
+    ctx->chem_cache.push_back(e);
+    *out = &ctx->chem_cache.back();
+    return MSSPE_OK;
+}
+
+int ensure_workspace(msspe_ctx *ctx, size_t cells_per_lane)
+{
+    if (ctx->ws_cells >= cells_per_lane) return MSSPE_OK;
+    if (ctx->wsS) (void)hipFree(ctx->wsS);
+    if (ctx->wsH) (void)hipFree(ctx->wsH);
+    ctx->wsS = ctx->wsH = nullptr;
+    ctx->ws_cells = 0;
+    const size_t bytes = cells_per_lane * kGenericLanes * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->wsS, bytes));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->wsH, bytes));
+    ctx->ws_cells = cells_per_lane;
+    return MSSPE_OK;
+}
+
+int ensure_overflow(msspe_ctx *ctx)
+{
+    if (ctx->ovf_list) return MSSPE_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)kChunkPairs));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 4));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
+    HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
+    return MSSPE_OK;
+}
+
+__global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total += *count;
+}
+
+bool use_generic_only()
+{
+    const char *e = std::getenv("MSSPE_FORCE_GENERIC");
+    return e && *e && *e != '0';
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *msspe_version(void) { return "msspe-hip 0.1.0 (gfx950)"; }
+
+void msspe_chem_ntthal_defaults(msspe_chem *c)
+{
+    if (!c) return;
+    c->mv = 50.0;
+    c->dv = 3.0;
+    c->dntp = 0.0;
+    c->dna_conc = 250.0;
+    c->temp_c = 25.0;
+    c->max_loop = 30;
+}
+
+void msspe_chem_primer3_defaults(msspe_chem *c)
+{
+    if (!c) return;
+    c->mv = 50.0;
+    c->dv = 1.5;
+    c->dntp = 0.6;
+    c->dna_conc = 50.0;
+    c->temp_c = 37.0;
+    c->max_loop = 30;
+}
+
+int msspe_create(int device, const char *params_path, msspe_ctx **out)
+{
+    if (!out) return MSSPE_ERR_ARG;
+    *out = nullptr;
+    msspe_ctx *ctx = new (std::nothrow) msspe_ctx();
+    if (!ctx) return MSSPE_ERR_NOMEM;
+    *out = ctx;   // returned even on failure so that msspe_last_error() works; destroy it anyway
+    ctx->device = device;
+    std::string err;
+    const std::string path = params_path && *params_path ? params_path : default_bundle_path();
+    if (!load_nn_tables(path, ctx->host_tb, err)) return fail(ctx, MSSPE_ERR_TABLES, err);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(ctx, MSSPE_ERR_DEVICE,
+                    "no HIP device available: this engine has no CPU fallback (needs gfx950)");
+    if (device < 0 || device >= ndev) return fail(ctx, MSSPE_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ctx, MSSPE_ERR_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tb, sizeof(NNTables)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tb, &ctx->host_tb, sizeof(NNTables), hipMemcpyHostToDevice));
+    return MSSPE_OK;
+}
+
+void msspe_destroy(msspe_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->own_stream) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->kmer.release();
+        for (auto &e : ctx->chem_cache)
+            if (e.d_pt) (void)hipFree(e.d_pt);
+        if (ctx->wsS) (void)hipFree(ctx->wsS);
+        if (ctx->wsH) (void)hipFree(ctx->wsH);
+        if (ctx->ovf_list) (void)hipFree(ctx->ovf_list);
+        if (ctx->ovf_count) (void)hipFree(ctx->ovf_count);
+        if (ctx->d_ovf_total) (void)hipFree(ctx->d_ovf_total);
+        if (ctx->d_tb) (void)hipFree(ctx->d_tb);
+        (void)hipStreamDestroy(ctx->own_stream);
+    }
+    delete ctx;
+}
+
+const char *msspe_last_error(const msspe_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int msspe_set_stream(msspe_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MSSPE_OK;
+}
+
+int msspe_synchronize(msspe_ctx *ctx)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MSSPE_OK;
+}
+
+int msspe_pack_oligos(const char *ascii, int n, int k, uint64_t *packed_out)
+{
+    if (!ascii || !packed_out || n < 0) return MSSPE_ERR_ARG;
+    if (k < 1 || k > 32) return MSSPE_ERR_K;
+    for (int i = 0; i < n; ++i) {
+        uint64_t w = 0;
+        for (int p = 0; p < k; ++p) {
+            uint64_t code;
+            switch (ascii[(size_t)i * k + p]) {
+            case 'A': case 'a': code = 0; break;
+            case 'C': case 'c': code = 1; break;
+            case 'G': case 'g': code = 2; break;
+            case 'T': case 't': code = 3; break;
+            default: return MSSPE_ERR_ARG;
+            }
+            w |= code << (2 * p);
+        }
+        packed_out[i] = w;
+    }
+    return MSSPE_OK;
+}
+
+void msspe_unpack_oligo(uint64_t packed, int k, char *ascii_out)
+{
+    for (int p = 0; p < k; ++p) ascii_out[p] = "ACGT"[(packed >> (2 * p)) & 3];
+    ascii_out[k] = 0;
+}
+
+int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
+                          const msspe_chem *chem, float dg_threshold, int row0, int row1,
+                          int col0, int col1, uint32_t *d_row_conflicts, uint64_t *d_bitmap,
+                          double *d_dg, double *d_tm)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_pool || !chem || n < 0) return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry");
+    if (k < 2 || k > 32) return fail(ctx, MSSPE_ERR_K, "oligo length must be 2..32");
+    if (row0 < 0 || row1 > n || row0 > row1 || col0 < 0 || col1 > n || col0 > col1)
+        return fail(ctx, MSSPE_ERR_ARG, "row/column range outside the pool");
+    if (row0 == row1 || col0 == col1) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ChemEntry *ce = nullptr;
+    int rc = chem_entry(ctx, *chem, dg_threshold, &ce);
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, (size_t)k * (size_t)k))) return rc;
+    if ((rc = ensure_overflow(ctx))) return rc;
+
+    const int ncols = col1 - col0;
+    const int words = (ncols + 63) / 64;
+    const bool fast = !use_generic_only() && k <= pairs_fast_max_k();
+    long rows_per_chunk = kChunkPairs / ncols;
+    if (rows_per_chunk < 1) rows_per_chunk = 1;   // a single row longer than the chunk: see below
+    for (int r = row0; r < row1; r += (int)rows_per_chunk) {
+        const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
+        for (int c0 = col0; c0 < col1; c0 += (int)kChunkPairs) {
+            const int c_end = (int)std::min<long>(col1, (long)c0 + kChunkPairs);
+            PairSinks sinks;
+            sinks.row_conflicts = d_row_conflicts;
+            // sub-block origin inside the caller's (row0, col0)-based outputs
+            sinks.row0 = row0;
+            sinks.col0 = col0;
+            sinks.ncols = ncols;
+            sinks.words = words;
+            sinks.bitmap = d_bitmap;
+            sinks.dg = d_dg;
+            sinks.tm = d_tm;
+            GenericDimerArgs g;
+            g.pt = ce->d_pt;
+            g.c[0] = ce->c[0];
+            g.c[1] = ce->c[1];
+            g.pool = d_pool;
+            g.k = k;
+            g.mode = 1;
+            g.self_mode = 0;
+            g.self_t = nullptr;
+            g.sinks = sinks;
+            g.wsS = ctx->wsS;
+            g.wsH = ctx->wsH;
+            g.ws_lanes = kGenericLanes;
+            if (fast) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, sizeof(uint32_t), ctx->stream));
+                PairKernelArgs a;
+                a.pt = ce->d_pt;
+                a.c = ce->c[0];
+                a.pool = d_pool;
+                a.n = n;
+                a.k = k;
+                a.row0 = r;
+                a.row1 = r_end;
+                a.col0 = c0;
+                a.col1 = c_end;
+                a.sinks = sinks;
+                a.overflow_list = ctx->ovf_list;
+                a.overflow_count = ctx->ovf_count;
+                a.overflow_cap = (uint32_t)kChunkPairs;
+                HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
+                g.list = ctx->ovf_list;
+                g.list_count = ctx->ovf_count;
+                g.n_work = (long)(r_end - r) * (long)(c_end - c0);
+                HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+                hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream,
+                                   ctx->ovf_count, ctx->d_ovf_total);
+            } else {
+                // matrix mode over the sub-block: explicit list-free addressing needs the
+                // sub-block to span whole output rows, so walk it row by row when it does not
+                if (c0 == col0 && c_end == col1) {
+                    g.list = nullptr;
+                    g.list_count = nullptr;
+                    g.sinks.row0 = r;   // matrix mode derives (row, col) from sinks.row0/col0
+                    g.n_work = (long)(r_end - r) * (long)ncols;
+                    // outputs are indexed relative to (row0, col0): shift the base pointers
+                    const size_t roff = (size_t)(r - row0);
+                    if (g.sinks.bitmap) g.sinks.bitmap += roff * (size_t)words;
+                    if (g.sinks.dg) g.sinks.dg += roff * (size_t)ncols;
+                    if (g.sinks.tm) g.sinks.tm += roff * (size_t)ncols;
+                    HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+                } else {
+                    return fail(ctx, MSSPE_ERR_ARG, "generic path: column range too wide");
+                }
+            }
+        }
+    }
+    return MSSPE_OK;
+}
+
+int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out)
+{
+    if (!ctx || !count_out) return MSSPE_ERR_ARG;
+    *count_out = 0;
+    if (!ctx->d_ovf_total) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(count_out, ctx->d_ovf_total, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
+    return MSSPE_OK;
+}
+
+int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
+                      const msspe_chem *chem, float dg_threshold, uint32_t *row_conflicts,
+                      uint64_t *bitmap, double *dg, double *tm)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!pool_ascii || !chem || n < 0) return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry");
+    if (n == 0) return MSSPE_OK;
+    std::vector<uint64_t> packed((size_t)n);
+    int rc = msspe_pack_oligos(pool_ascii, n, k, packed.data());
+    if (rc) return fail(ctx, rc, rc == MSSPE_ERR_K ? "oligo length must be 1..32"
+                                                   : "pool holds characters other than ACGT");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t words = ((size_t)n + 63) / 64, nn = (size_t)n * (size_t)n;
+    uint64_t *d_pool = nullptr, *d_bitmap = nullptr;
+    uint32_t *d_rc = nullptr;
+    double *d_dg = nullptr, *d_tm = nullptr;
+    auto cleanup = [&]() {
+        if (d_pool) (void)hipFree(d_pool);
+        if (d_bitmap) (void)hipFree(d_bitmap);
+        if (d_rc) (void)hipFree(d_rc);
+        if (d_dg) (void)hipFree(d_dg);
+        if (d_tm) (void)hipFree(d_tm);
+    };
+#define TRY_OR_CLEAN(expr)                                         \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) {                                   \
+            cleanup();                                             \
+            return hip_fail(ctx, e__, #expr);                      \
+        }                                                          \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc((void **)&d_pool, sizeof(uint64_t) * (size_t)n));
+    TRY_OR_CLEAN(hipMemcpy(d_pool, packed.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
+    if (row_conflicts) {
+        TRY_OR_CLEAN(hipMalloc((void **)&d_rc, sizeof(uint32_t) * (size_t)n));
+        TRY_OR_CLEAN(hipMemset(d_rc, 0, sizeof(uint32_t) * (size_t)n));
+    }
+    if (bitmap) {
+        TRY_OR_CLEAN(hipMalloc((void **)&d_bitmap, sizeof(uint64_t) * (size_t)n * words));
+        TRY_OR_CLEAN(hipMemset(d_bitmap, 0, sizeof(uint64_t) * (size_t)n * words));
+    }
+    if (dg) TRY_OR_CLEAN(hipMalloc((void **)&d_dg, sizeof(double) * nn));
+    if (tm) TRY_OR_CLEAN(hipMalloc((void **)&d_tm, sizeof(double) * nn));
+    rc = msspe_cross_dimer_dev(ctx, d_pool, n, k, chem, dg_threshold, 0, n, 0, n, d_rc, d_bitmap,
+                               d_dg, d_tm);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipStreamSynchronize(ctx->stream));
+    if (row_conflicts)
+        TRY_OR_CLEAN(hipMemcpy(row_conflicts, d_rc, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    if (bitmap)
+        TRY_OR_CLEAN(hipMemcpy(bitmap, d_bitmap, sizeof(uint64_t) * (size_t)n * words, hipMemcpyDeviceToHost));
+    if (dg) TRY_OR_CLEAN(hipMemcpy(dg, d_dg, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    if (tm) TRY_OR_CLEAN(hipMemcpy(tm, d_tm, sizeof(double) * nn, hipMemcpyDeviceToHost));
+    cleanup();
+    return MSSPE_OK;
+}
+
+int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
+                          const msspe_chem *chem, double *d_tm, double *d_gc, double *d_self_any,
+                          double *d_self_end, double *d_hairpin)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_pool || !chem || n < 0) return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry");
+    if (k < 2 || k > 32) return fail(ctx, MSSPE_ERR_K, "oligo length must be 2..32");
+    if (n == 0) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ChemEntry *ce = nullptr;
+    int rc = chem_entry(ctx, *chem, -9000.0f, &ce);   // threshold unused by the self modes
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, (size_t)(k + 1) * (size_t)(k + 1)))) return rc;
+    if (d_tm || d_gc)
+        HIP_TRY(ctx, launch_oligo_tm(d_pool, n, k, chem->dna_conc, chem->mv, chem->dv, chem->dntp,
+                                     d_tm, d_gc, ctx->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        double *dst = pass == 0 ? d_self_any : d_self_end;
+        if (!dst) continue;
+        GenericDimerArgs g;
+        std::memset(&g, 0, sizeof g);
+        g.pt = ce->d_pt;
+        g.c[0] = ce->c[0];
+        g.c[1] = ce->c[1];
+        g.pool = d_pool;
+        g.k = k;
+        g.mode = pass == 0 ? 1 : 2;
+        g.n_work = n;
+        g.self_mode = 1;
+        g.self_t = dst;
+        g.wsS = ctx->wsS;
+        g.wsH = ctx->wsH;
+        g.ws_lanes = kGenericLanes;
+        HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+    }
+    if (d_hairpin) {
+        HairpinArgs h;
+        h.tb = ctx->d_tb;
+        h.c = make_hairpin_consts(chem->mv, chem->dv, chem->dntp, chem->temp_c + 273.15,
+                                  chem->max_loop);
+        h.pool = d_pool;
+        h.k = k;
+        h.n_work = n;
+        h.out_t = d_hairpin;
+        h.wsS = ctx->wsS;
+        h.wsH = ctx->wsH;
+        h.ws_lanes = kGenericLanes;
+        HIP_TRY(ctx, launch_hairpin_generic(h, ctx->stream));
+    }
+    return MSSPE_OK;
+}
+
+int msspe_oligo_stats(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
+                      const msspe_chem *chem, double *tm, double *gc, double *self_any,
+                      double *self_end, double *hairpin)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!pool_ascii || !chem || n < 0) return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry");
+    if (n == 0) return MSSPE_OK;
+    std::vector<uint64_t> packed((size_t)n);
+    int rc = msspe_pack_oligos(pool_ascii, n, k, packed.data());
+    if (rc) return fail(ctx, rc, rc == MSSPE_ERR_K ? "oligo length must be 1..32"
+                                                   : "pool holds characters other than ACGT");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t *d_pool = nullptr;
+    double *d_out = nullptr;
+    const size_t nb = sizeof(double) * (size_t)n;
+    HIP_TRY(ctx, hipMalloc((void **)&d_pool, sizeof(uint64_t) * (size_t)n));
+    hipError_t e = hipMalloc((void **)&d_out, nb * 5);
+    if (e != hipSuccess) {
+        (void)hipFree(d_pool);
+        return hip_fail(ctx, e, "hipMalloc");
+    }
+    (void)hipMemcpy(d_pool, packed.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice);
+    double *host[5] = {tm, gc, self_any, self_end, hairpin};
+    double *dev[5];
+    for (int q = 0; q < 5; ++q) dev[q] = host[q] ? d_out + (size_t)q * n : nullptr;
+    rc = msspe_oligo_stats_dev(ctx, d_pool, n, k, chem, dev[0], dev[1], dev[2], dev[3], dev[4]);
+    if (!rc) {
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "hipStreamSynchronize");
+    }
+    for (int q = 0; q < 5 && !rc; ++q)
+        if (host[q]) {
+            e = hipMemcpy(host[q], dev[q], nb, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpy");
+        }
+    (void)hipFree(d_pool);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int msspe_kmer_candidates_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, size_t seq_len,
+                              const msspe_kmer_opt *opt, int direction, uint64_t *words_out,
+                              uint32_t *freq_out, int capacity, int *n_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_seqs || !opt || !words_out || !freq_out || !n_out || capacity < 0)
+        return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = ctx->kmer.run(d_seqs, n_seq, seq_len, *opt, direction, words_out, freq_out,
+                                 capacity, n_out, ctx->stream, err);
+    if (rc) return fail(ctx, rc, err);
+    return MSSPE_OK;
+}
+
+int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
+                          const msspe_kmer_opt *opt, int direction, uint64_t *words_out,
+                          uint32_t *freq_out, int capacity, int *n_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!seqs || n_seq < 0) return fail(ctx, MSSPE_ERR_ARG, "null sequences");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t *d = nullptr;
+    const size_t bytes = (size_t)n_seq * seq_len;
+    HIP_TRY(ctx, hipMalloc((void **)&d, bytes ? bytes : 1));
+    hipError_t e = hipMemcpy(d, seqs, bytes, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? msspe_kmer_candidates_dev(ctx, d, n_seq, seq_len, opt, direction,
+                                                         words_out, freq_out, capacity, n_out)
+                             : hip_fail(ctx, e, "hipMemcpy");
+    (void)hipFree(d);
+    return rc;
+}
+
+float msspe_round_g_f32(double x) { return round_g_f32(x); }
+float msspe_round_fixed_f32(double x, int decimals) { return round_fixed_f32(x, decimals); }
+double msspe_g_cut(float threshold) { return g_cut(threshold); }
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// kernels.hpp -- launch interface between the C ABI (capi.cpp) and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "nn_params.hpp"
+
+namespace msspe {
+
+// Where the results of one ordered pair go (all pointers optional, device memory).
+struct PairSinks {
+    uint32_t *row_conflicts;   // [n]            += 1 per conflicting column
+    uint64_t *bitmap;          // [(row1-row0) * words]
+    double *dg;                // [(row1-row0) * (col1-col0)]
+    double *tm;                // [(row1-row0) * (col1-col0)]
+    int row0, col0, ncols, words;
+};
+
+// Generic dense-DP dimer kernel.
+//   list != nullptr : work item w = ordered pair (list[w].x, list[w].y) of pool indices
+//   list == nullptr : work item w = (row0 + w / ncols, col0 + w % ncols)  (matrix mode)
+//   self_mode       : work item w = (w, w); results go to self_t[w] = max(0, t)
+// pt[0] / c[0]: ordinary pairs; pt[1] / c[1]: both oligos self-complementary (RC differs).
+struct GenericDimerArgs {
+    const PairTables *pt;      // device, 2 entries
+    ThalConsts c[2];
+    const uint64_t *pool;
+    int k;
+    int mode;                  // kModeAny / kModeEnd1
+    const uint2 *list;
+    const uint32_t *list_count;   // optional device counter overriding n_work (overflow lists)
+    long n_work;
+    int self_mode;
+    double *self_t;
+    PairSinks sinks;
+    double *wsS, *wsH;         // workspace planes, [cell][lane], lanes = ws_lanes
+    size_t ws_lanes;
+};
+hipError_t launch_dimer_generic(const GenericDimerArgs &a, hipStream_t stream);
+
+// Generic hairpin kernel: one lane per oligo; out_t[w] = max(0, t).
+struct HairpinArgs {
+    const NNTables *tb;        // device
+    ThalConsts c;
+    const uint64_t *pool;
+    int k;
+    long n_work;
+    double *out_t;
+    double *wsS, *wsH;         // (k+2)^2 planes per lane, [cell][lane]
+    size_t ws_lanes;
+};
+hipError_t launch_hairpin_generic(const HairpinArgs &a, hipStream_t stream);
+
+// oligotm + GC%: one lane per oligo.
+hipError_t launch_oligo_tm(const uint64_t *pool, int n, int k, double dna_conc, double mv,
+                           double dv, double dntp, double *tm, double *gc, hipStream_t stream);
+
+// Tuned all-pairs kernel (thal ANY, k <= 16, ordinary pairs).  Pairs whose DP does not fit the
+// register-resident table are appended to overflow_list (capacity overflow_cap) and must be
+// finished by launch_dimer_generic.
+struct PairKernelArgs {
+    const PairTables *pt;      // device, entry 0
+    ThalConsts c;
+    const uint64_t *pool;
+    int n, k;
+    int row0, row1, col0, col1;
+    PairSinks sinks;
+    uint2 *overflow_list;
+    uint32_t *overflow_count;
+    uint32_t overflow_cap;
+};
+hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
+int pairs_fast_max_k();
+
+}  // namespace msspe

@@ -1,0 +1,30 @@
+// kmer_stage.hpp -- stage A on the device: k-mer candidate generation
+// (replaces get_segment_manager + find_candidates_kmers,
+//  /root/reference/od-msspe/src/main.rs:196-235 and :331-406).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/msspe_hip.h"
+
+namespace msspe {
+
+class KmerStage {
+public:
+    // d_seqs: device, n_seq x seq_len bytes.  words_out / freq_out / n_out: host buffers.
+    int run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+            int direction, uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out,
+            hipStream_t stream, std::string &err);
+    void release();
+
+private:
+    void *buf_[16] = {};
+    size_t cap_[16] = {};
+    int ensure(int slot, size_t bytes, std::string &err);
+};
+
+}  // namespace msspe

@@ -1,0 +1,444 @@
+// nn_params.cpp -- host loader for the nearest-neighbour tables, the per-chemistry constants and
+// the compact device tables of the all-pairs kernel.
+//
+// Replaces, on the host side, what ntthal does at start-up with `-path`
+// (/root/reference/od-msspe/src/delta_g.rs:90,107-108): Primer3 2.6.1 thal.c get_thermodynamic_values()
+// and its getStack / getStackint2 / getTstack / getTstack2 / getDangle / getLoop / getTriloop /
+// getTetraloop readers, restated from SURVEY.md Appendix C.1.
+#include "nn_params.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <sys/stat.h>
+
+namespace msspe {
+namespace {
+
+using Tokens = std::vector<std::string>;
+
+const char *const kSections[] = {"stack.ds", "stack.dh", "stackmm.ds", "stackmm.dh",
+                                 "tstack_tm_inf.ds", "tstack.dh", "tstack2.ds", "tstack2.dh",
+                                 "dangle.ds", "dangle.dh", "loops.ds", "loops.dh",
+                                 "triloop.ds", "triloop.dh", "tetraloop.ds", "tetraloop.dh"};
+
+bool read_tokens(const std::string &path, Tokens &out)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string tok;
+    while (f >> tok) out.push_back(tok);
+    return true;
+}
+
+double number(const std::string &tok)
+{
+    if (tok.compare(0, 3, "inf") == 0) return INFINITY;   // Primer3's spelling of "not available"
+    return std::strtod(tok.c_str(), nullptr);
+}
+
+int code(char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return kBaseN;
+    }
+}
+
+// A four-index table as laid out in the files: 256 numbers, index ((a*4+b)*4+c)*4+d.
+// mode 0: any N or any non-finite entry -> (-1, +inf)                       (stack, stackmm)
+// mode 1: a or c = N -> (-1, +inf); b or d = N -> (1e-11, 0)               (tstack, tstack2)
+bool fill4(const Tokens &ds, const Tokens &dh, int mode, double S[5][5][5][5],
+           double H[5][5][5][5])
+{
+    if (ds.size() != 256 || dh.size() != 256) return false;
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b)
+            for (int c = 0; c < 5; ++c)
+                for (int d = 0; d < 5; ++d) {
+                    double s = -1.0, h = INFINITY;
+                    const bool inner_n = (a == 4 || c == 4), outer_n = (b == 4 || d == 4);
+                    if (mode == 1 && !inner_n && outer_n) {
+                        s = 0.00000000001;
+                        h = 0.0;
+                    } else if (!inner_n && !outer_n) {
+                        const int k = ((a * 4 + b) * 4 + c) * 4 + d;
+                        s = number(ds[k]);
+                        h = number(dh[k]);
+                        if (!std::isfinite(s) || !std::isfinite(h)) {
+                            s = -1.0;
+                            h = INFINITY;
+                        }
+                    }
+                    S[a][b][c][d] = s;
+                    H[a][b][c][d] = h;
+                }
+    return true;
+}
+
+bool fill_dangles(const Tokens &ds, const Tokens &dh, NNTables &t)
+{
+    if (ds.size() != 128 || dh.size() != 128) return false;
+    for (int x = 0; x < 5; ++x)
+        for (int y = 0; y < 5; ++y)
+            for (int z = 0; z < 5; ++z) {
+                t.d3S[x][y][z] = t.d5S[x][y][z] = -1.0;
+                t.d3H[x][y][z] = t.d5H[x][y][z] = INFINITY;
+            }
+    // 3' block: file index X*16 + Z*4 + Y ; 5' block: 64 + Z*16 + X*4 + Y
+    for (int p = 0; p < 4; ++p)
+        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) {
+                const int k = p * 16 + q * 4 + r;
+                double s = number(ds[k]), h = number(dh[k]);
+                if (std::isfinite(s) && std::isfinite(h)) {
+                    t.d3S[p][r][q] = s;
+                    t.d3H[p][r][q] = h;
+                }
+                s = number(ds[64 + k]);
+                h = number(dh[64 + k]);
+                if (std::isfinite(s) && std::isfinite(h)) {
+                    t.d5S[p][q][r] = s;
+                    t.d5H[p][q][r] = h;
+                }
+            }
+    return true;
+}
+
+bool fill_loops(const Tokens &ds, const Tokens &dh, NNTables &t)
+{
+    if (ds.size() != 120 || dh.size() != 120) return false;
+    for (int k = 0; k < 30; ++k) {
+        t.interiorS[k] = number(ds[4 * k + 1]);
+        t.bulgeS[k] = number(ds[4 * k + 2]);
+        t.hairpinS[k] = number(ds[4 * k + 3]);
+        t.interiorH[k] = number(dh[4 * k + 1]);
+        t.bulgeH[k] = number(dh[4 * k + 2]);
+        t.hairpinH[k] = number(dh[4 * k + 3]);
+    }
+    return true;
+}
+
+// tri-/tetraloop files hold the same keys in .ds and .dh; Primer3 looks each file up on its own.
+bool fill_tloops(const Tokens &ds, const Tokens &dh, size_t keylen, int cap, uint32_t *keys,
+                 double *S, double *H, int &n)
+{
+    std::map<uint32_t, std::pair<double, double>> m;
+    auto pack = [&](const std::string &key, uint32_t &out) {
+        if (key.size() != keylen) return false;
+        out = 0;
+        for (char ch : key) out = (out << 3) | (uint32_t)code(ch);
+        return true;
+    };
+    if (ds.size() % 2 || dh.size() % 2) return false;
+    for (size_t i = 0; i + 1 < ds.size(); i += 2) {
+        uint32_t k;
+        if (!pack(ds[i], k)) return false;
+        if (!m.count(k)) m[k] = {0.0, 0.0};
+        m[k].first = number(ds[i + 1]);
+    }
+    for (size_t i = 0; i + 1 < dh.size(); i += 2) {
+        uint32_t k;
+        if (!pack(dh[i], k)) return false;
+        if (!m.count(k)) m[k] = {0.0, 0.0};
+        m[k].second = number(dh[i + 1]);
+    }
+    if ((int)m.size() > cap) return false;
+    n = 0;
+    for (auto &kv : m) {
+        keys[n] = kv.first;
+        S[n] = kv.second.first;
+        H[n] = kv.second.second;
+        ++n;
+    }
+    return true;
+}
+
+bool assemble(std::map<std::string, Tokens> &sec, NNTables &t, std::string &err)
+{
+    for (const char *name : kSections)
+        if (!sec.count(name)) {
+            err = std::string("thermodynamic table missing: ") + name;
+            return false;
+        }
+    std::memset(&t, 0, sizeof t);
+    bool ok = fill4(sec["stack.ds"], sec["stack.dh"], 0, t.stackS, t.stackH) &&
+              fill4(sec["stackmm.ds"], sec["stackmm.dh"], 0, t.mmS, t.mmH) &&
+              fill4(sec["tstack_tm_inf.ds"], sec["tstack.dh"], 1, t.tstackS, t.tstackH) &&
+              fill4(sec["tstack2.ds"], sec["tstack2.dh"], 1, t.tstack2S, t.tstack2H) &&
+              fill_dangles(sec["dangle.ds"], sec["dangle.dh"], t) &&
+              fill_loops(sec["loops.ds"], sec["loops.dh"], t) &&
+              fill_tloops(sec["triloop.ds"], sec["triloop.dh"], 5, 32, t.triKey, t.triS, t.triH,
+                          t.n_tri) &&
+              fill_tloops(sec["tetraloop.ds"], sec["tetraloop.dh"], 6, 128, t.tetKey, t.tetS,
+                          t.tetH, t.n_tet);
+    if (!ok) err = "thermodynamic tables malformed (wrong token count)";
+    return ok;
+}
+
+double at_S(int a, int b) { return (a + b == 3 && (a == 0 || a == 3)) ? 6.9 : 0.0; }
+double at_H(int a, int b) { return (a + b == 3 && (a == 0 || a == 3)) ? 2200.0 : 0.0; }
+bool pairs(int a, int b) { return a < 4 && b < 4 && a + b == 3; }
+
+}  // namespace
+
+bool load_nn_tables(const std::string &path, NNTables &out, std::string &err)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) {
+        err = "cannot stat thermodynamic parameter path: " + path;
+        return false;
+    }
+    std::map<std::string, Tokens> sec;
+    if (S_ISDIR(st.st_mode)) {
+        for (const char *name : kSections) {
+            std::string p = path;
+            if (!p.empty() && p.back() != '/') p += '/';
+            if (!read_tokens(p + name, sec[name])) {
+                err = "cannot read " + p + name;
+                return false;
+            }
+        }
+    } else {
+        Tokens all;
+        if (!read_tokens(path, all)) {
+            err = "cannot read " + path;
+            return false;
+        }
+        size_t i = 0;
+        while (i < all.size() && all[i] != "@") ++i;   // skip the '#' comment header
+        while (i < all.size()) {
+            if (all[i] != "@" || i + 2 >= all.size()) {
+                err = "bundle syntax error in " + path;
+                return false;
+            }
+            const std::string name = all[i + 1];
+            const size_t cnt = (size_t)std::strtoul(all[i + 2].c_str(), nullptr, 10);
+            i += 3;
+            if (i + cnt > all.size()) {
+                err = "bundle truncated in section " + name;
+                return false;
+            }
+            sec[name].assign(all.begin() + (long)i, all.begin() + (long)(i + cnt));
+            i += cnt;
+        }
+    }
+    return assemble(sec, out, err);
+}
+
+// thal.c saltCorrectS()
+static double salt_correction(double mv, double dv, double dntp)
+{
+    if (dv <= 0) dntp = dv;
+    return 0.368 * (std::log((mv + 120 * (std::sqrt(std::fmax(0.0, dv - dntp)))) / 1000));
+}
+
+ThalConsts make_dimer_consts(double mv, double dv, double dntp, double dna_conc, double temp_c,
+                             int max_loop, bool both_self_complementary, float dg_threshold)
+{
+    ThalConsts c;
+    c.init_S = -5.7;
+    c.init_H = 200;
+    c.RC = 1.9872 * std::log(dna_conc / (both_self_complementary ? 1000000000.0 : 4000000000.0));
+    c.salt = salt_correction(mv, dv, dntp);
+    c.temp_k = temp_c + 273.15;
+    c.g_cut = g_cut(dg_threshold);
+    c.max_loop = max_loop;
+    return c;
+}
+
+ThalConsts make_hairpin_consts(double mv, double dv, double dntp, double temp_k, int max_loop)
+{
+    ThalConsts c;
+    c.init_S = -0.00000000001;
+    c.init_H = 0.0;
+    c.RC = 0;
+    c.salt = salt_correction(mv, dv, dntp);
+    c.temp_k = temp_k;
+    c.g_cut = 0;
+    c.max_loop = max_loop;
+    return c;
+}
+
+void end_term(const NNTables &t, const ThalConsts &c, int a, int b, int oa, int ob, bool left,
+              double &outS, double &outH)
+{
+    const double T37 = 310.15;
+    if (!pairs(a, b)) {
+        outS = -1.0;
+        outH = INFINITY;
+        return;
+    }
+    double tS, tH, d3S, d3H, d5S, d5H;
+    if (left) {   // outer bases i-1 / j-1; strand 2 is the "first" strand of the lookup
+        tS = t.tstack2S[b][ob][a][oa];
+        tH = t.tstack2H[b][ob][a][oa];
+        d3S = t.d3S[b][ob][a];
+        d3H = t.d3H[b][ob][a];
+        d5S = t.d5S[b][a][oa];
+        d5H = t.d5H[b][a][oa];
+    } else {      // outer bases i+1 / j+1
+        tS = t.tstack2S[a][oa][b][ob];
+        tH = t.tstack2H[a][oa][b][ob];
+        d3S = t.d3S[a][oa][b];
+        d3H = t.d3H[a][oa][b];
+        d5S = t.d5S[a][b][ob];
+        d5H = t.d5H[a][b][ob];
+    }
+    const double aS = at_S(a, b), aH = at_H(a, b);
+    // option T: terminal mismatch stack
+    double S1 = aS + tS, H1 = aH + tH, G1 = H1 - T37 * S1, T1 = -INFINITY;
+    if (!std::isfinite(H1) || G1 > 0) {
+        H1 = INFINITY;
+        S1 = -1.0;
+        G1 = 1.0;
+    }
+    // option D: dangling ends, only when the outer bases cannot pair
+    bool haveD = false;
+    double S2 = -1.0, H2 = INFINITY;
+    if (!pairs(oa, ob)) {
+        if (std::isfinite(d3H) && std::isfinite(d5H)) {
+            S2 = aS + d3S + d5S;
+            H2 = aH + d3H + d5H;
+            haveD = true;
+        } else if (std::isfinite(d3H)) {
+            S2 = aS + d3S;
+            H2 = aH + d3H;
+            haveD = true;
+        } else if (std::isfinite(d5H)) {
+            S2 = aS + d5S;
+            H2 = aH + d5H;
+            haveD = true;
+        }
+    }
+    if (haveD) {
+        double G2 = H2 - T37 * S2;
+        if (!std::isfinite(H2) || G2 > 0) {
+            H2 = INFINITY;
+            S2 = -1.0;
+            G2 = 1.0;
+        }
+        const double T2 = (H2 + c.init_H) / (S2 + c.init_S + c.RC);
+        if (std::isfinite(H1) && G1 < 0) {
+            T1 = (H1 + c.init_H) / (S1 + c.init_S + c.RC);
+            if (T1 < T2 && G2 < 0) {
+                S1 = S2;
+                H1 = H2;
+                T1 = T2;
+            }
+        } else if (G2 < 0) {
+            S1 = S2;
+            H1 = H2;
+            T1 = T2;
+        }
+    }
+    // bare closing pair; T1 is still -inf when no dangle option was considered (Primer3 quirk)
+    const double Tb = (aH + c.init_H) / (aS + c.init_S + c.RC);
+    if (std::isfinite(H1) && !(T1 < Tb)) {
+        outS = S1;
+        outH = H1;
+    } else {
+        outS = aS;
+        outH = aH;
+    }
+}
+
+bool build_pair_tables(const NNTables &t, const ThalConsts &c, PairTables &out, std::string &err)
+{
+    std::memset(&out, 0, sizeof out);
+    bool integral = true;
+    auto as_int = [&](double h) -> int32_t {
+        if (!std::isfinite(h)) return kHInf;
+        if (h != std::nearbyint(h) || std::fabs(h) > 1e6) integral = false;
+        return (int32_t)h;
+    };
+    for (int a = 0; a < 4; ++a)
+        for (int oa = 0; oa < 5; ++oa)
+            for (int ob = 0; ob < 5; ++ob) {
+                const int idx = a * 25 + oa * 5 + ob;
+                double S, H;
+                end_term(t, c, a, 3 - a, oa, ob, true, S, H);
+                out.endL_S[idx] = S;
+                out.endL_H[idx] = as_int(H);
+                end_term(t, c, a, 3 - a, oa, ob, false, S, H);
+                out.endR_S[idx] = S;
+                out.endR_H[idx] = as_int(H);
+            }
+    for (int x = 0; x < 4; ++x)
+        for (int y = 0; y < 4; ++y) {
+            out.wc_S[x * 4 + y] = t.stackS[x][y][3 - x][3 - y];
+            out.wc_H[x * 4 + y] = as_int(t.stackH[x][y][3 - x][3 - y]);
+            for (int z = 0; z < 4; ++z) {
+                const int idx = (x * 4 + y) * 4 + z;
+                out.ts_S[idx] = t.tstackS[x][y][3 - x][z];
+                out.ts_H[idx] = as_int(t.tstackH[x][y][3 - x][z]);
+                out.mm_S[idx] = t.mmS[x][y][3 - x][z];
+                out.mm_H[idx] = as_int(t.mmH[x][y][3 - x][z]);
+            }
+        }
+    for (int k = 0; k < 32; ++k) {
+        out.loopS[0][k] = k < 30 ? t.interiorS[k] : -1.0;
+        out.loopH[0][k] = k < 30 ? as_int(t.interiorH[k]) : kHInf;
+        out.loopS[1][k] = k < 30 ? t.bulgeS[k] : -1.0;
+        out.loopH[1][k] = k < 30 ? as_int(t.bulgeH[k]) : kHInf;
+    }
+    out.h_is_integral = integral ? 1 : 0;
+    if (!integral) err = "enthalpy tables are not integral: the all-pairs kernel cannot be used";
+    return integral;
+}
+
+float round_g_f32(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%g", x);
+    return std::strtof(buf, nullptr);
+}
+
+float round_fixed_f32(double x, int decimals)
+{
+    char buf[400];
+    std::snprintf(buf, sizeof buf, "%.*f", decimals, x);
+    return std::strtof(buf, nullptr);
+}
+
+// Doubles ordered as unsigned integers: monotone map double -> uint64.
+static uint64_t ordered_key(double d)
+{
+    uint64_t k;
+    std::memcpy(&k, &d, sizeof k);
+    return (k & 0x8000000000000000ull) ? ~k : (k | 0x8000000000000000ull);
+}
+static double from_key(uint64_t k)
+{
+    k = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    double d;
+    std::memcpy(&d, &k, sizeof d);
+    return d;
+}
+
+double g_cut(float threshold)
+{
+    // decision(x) = round_g_f32(x) < threshold is monotone (true for small x).  Return the
+    // largest double for which it is true, so that the kernels can test dG <= cut.
+    if (std::isnan(threshold)) return -INFINITY;
+    auto dec = [&](double x) { return round_g_f32(x) < threshold; };
+    uint64_t lo = ordered_key(-DBL_MAX), hi = ordered_key(DBL_MAX);
+    if (!dec(from_key(lo))) return -INFINITY;
+    if (dec(from_key(hi))) return DBL_MAX;
+    while (hi - lo > 1) {   // invariant: dec(lo) true, dec(hi) false
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (dec(from_key(mid))) lo = mid;
+        else hi = mid;
+    }
+    return from_key(lo);
+}
+
+}  // namespace msspe

@@ -1,0 +1,239 @@
+"""ctypes binding of include/msspe_hip.h.  Fails loudly when the HIP library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent.parent          # open-msspe-design_amd/
+STATUS = {0: "MSSPE_OK", 1: "MSSPE_ERR_ARG", 2: "MSSPE_ERR_K", 3: "MSSPE_ERR_TABLES",
+          4: "MSSPE_ERR_DEVICE", 5: "MSSPE_ERR_CAPACITY", 6: "MSSPE_ERR_NOMEM"}
+
+# every symbol include/msspe_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "msspe_chem_ntthal_defaults", "msspe_chem_primer3_defaults", "msspe_create", "msspe_destroy",
+    "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_synchronize",
+    "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
+    "msspe_last_overflow_pairs", "msspe_oligo_stats_dev", "msspe_oligo_stats",
+    "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
+    "msspe_round_fixed_f32", "msspe_g_cut",
+]
+
+
+class MsspeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Chem(C.Structure):
+    """msspe_chem: what od-msspe passes to ntthal (od-msspe/src/delta_g.rs:93-110)."""
+    _fields_ = [("mv", C.c_double), ("dv", C.c_double), ("dntp", C.c_double),
+                ("dna_conc", C.c_double), ("temp_c", C.c_double), ("max_loop", C.c_int)]
+
+    @classmethod
+    def ntthal(cls, mv=50.0, dv=3.0, dntp=0.0, dna_conc=250.0, temp_c=25.0, max_loop=30):
+        return cls(mv, dv, dntp, dna_conc, temp_c, max_loop)
+
+    @classmethod
+    def primer3(cls):
+        return cls(50.0, 1.5, 0.6, 50.0, 37.0, 30)
+
+
+class KmerOpt(C.Structure):
+    """msspe_kmer_opt: od-msspe/src/constants.rs:1-5 defaults."""
+    _fields_ = [("segment_size", C.c_int), ("overlap_size", C.c_int),
+                ("search_window_size", C.c_int), ("kmer_size", C.c_int),
+                ("max_iterations", C.c_int), ("max_mismatch_segments", C.c_int)]
+
+
+def lib_path() -> Path:
+    return PKG_DIR / "libmsspe_hip.so"
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise ImportError(f"{p} is missing: build it with open-msspe-design_amd/build.sh "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(str(p))
+    vp, u64p = C.c_void_p, C.c_void_p
+    L.msspe_version.restype = C.c_char_p
+    L.msspe_last_error.restype = C.c_char_p
+    L.msspe_last_error.argtypes = [vp]
+    L.msspe_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.msspe_destroy.argtypes = [vp]
+    L.msspe_set_stream.argtypes = [vp, vp]
+    L.msspe_synchronize.argtypes = [vp]
+    L.msspe_pack_oligos.argtypes = [C.c_char_p, C.c_int, C.c_int, u64p]
+    L.msspe_unpack_oligo.argtypes = [C.c_uint64, C.c_int, C.c_char_p]
+    L.msspe_cross_dimer_dev.argtypes = [vp, u64p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.msspe_cross_dimer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
+                                    vp, vp, vp, vp]
+    L.msspe_last_overflow_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.msspe_oligo_stats_dev.argtypes = [vp, u64p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
+    L.msspe_oligo_stats.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
+    L.msspe_kmer_candidates.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), C.c_int,
+                                        vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.msspe_kmer_candidates_dev.argtypes = L.msspe_kmer_candidates.argtypes
+    L.msspe_round_g_f32.restype = C.c_float
+    L.msspe_round_g_f32.argtypes = [C.c_double]
+    L.msspe_round_fixed_f32.restype = C.c_float
+    L.msspe_round_fixed_f32.argtypes = [C.c_double, C.c_int]
+    L.msspe_g_cut.restype = C.c_double
+    L.msspe_g_cut.argtypes = [C.c_float]
+    _lib = L
+    return L
+
+
+def pack_oligos(oligos) -> np.ndarray:
+    """list[str] or uint8 (n,k) ASCII -> uint64[n] (2 bits per base, base p at bits 2p..2p+1)."""
+    if isinstance(oligos, np.ndarray):
+        n, k = oligos.shape
+        buf = np.ascontiguousarray(oligos, dtype=np.uint8).tobytes()
+    else:
+        n = len(oligos)
+        k = len(oligos[0]) if n else 0
+        if any(len(o) != k for o in oligos):
+            raise MsspeError(1, "oligos must all have the same length")
+        buf = "".join(oligos).encode()
+    out = np.zeros(n, dtype=np.uint64)
+    rc = load_library().msspe_pack_oligos(buf, n, k, out.ctypes.data)
+    if rc:
+        raise MsspeError(rc, "pool holds characters other than ACGT" if rc == 1 else "bad oligo length")
+    return out
+
+
+def unpack_oligo(word: int, k: int) -> str:
+    buf = C.create_string_buffer(k + 1)
+    load_library().msspe_unpack_oligo(C.c_uint64(int(word)), k, buf)
+    return buf.value.decode()
+
+
+def round_g_f32(x: float) -> float:
+    return float(load_library().msspe_round_g_f32(x))
+
+
+def round_fixed_f32(x: float, decimals: int) -> float:
+    return float(load_library().msspe_round_fixed_f32(x, decimals))
+
+
+def g_cut(threshold: float) -> float:
+    return float(load_library().msspe_g_cut(C.c_float(threshold)))
+
+
+def _ascii(oligos):
+    if isinstance(oligos, np.ndarray):
+        n, k = oligos.shape
+        return np.ascontiguousarray(oligos, dtype=np.uint8).tobytes(), n, k
+    n = len(oligos)
+    k = len(oligos[0]) if n else 0
+    return "".join(oligos).encode(), n, k
+
+
+class Engine:
+    """One msspe_ctx bound to one device."""
+
+    def __init__(self, device: int = 0, params_path: str | None = None):
+        self.L = load_library()
+        self.ptr = C.c_void_p()
+        rc = self.L.msspe_create(device, params_path.encode() if params_path else None,
+                                 C.byref(self.ptr))
+        if rc:
+            msg = self.L.msspe_last_error(self.ptr).decode() if self.ptr else "allocation failed"
+            if self.ptr:
+                self.L.msspe_destroy(self.ptr)
+                self.ptr = C.c_void_p()
+            raise MsspeError(rc, msg)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.L.msspe_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise MsspeError(rc, self.L.msspe_last_error(self.ptr).decode())
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self.L.msspe_set_stream(self.ptr, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._check(self.L.msspe_synchronize(self.ptr))
+
+    # ---- stage C ---------------------------------------------------------------------------
+    def cross_dimer(self, pool, chem: Chem | None = None, threshold: float = -9000.0,
+                    want_dg=True, want_tm=False, want_bitmap=True):
+        """Host-buffer call: returns dict(row_conflicts, bitmap, dg, tm) for the full n x n matrix."""
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.ntthal()
+        words = (n + 63) // 64
+        rc_ = np.zeros(n, dtype=np.uint32)
+        bm = np.zeros((n, words), dtype=np.uint64) if want_bitmap else None
+        dg = np.empty((n, n)) if want_dg else None
+        tm = np.empty((n, n)) if want_tm else None
+        self._check(self.L.msspe_cross_dimer(
+            self.ptr, buf, n, k, C.byref(chem), C.c_float(threshold), rc_.ctypes.data,
+            bm.ctypes.data if want_bitmap else None, dg.ctypes.data if want_dg else None,
+            tm.ctypes.data if want_tm else None))
+        return {"row_conflicts": rc_, "bitmap": bm, "dg": dg, "tm": tm}
+
+    def cross_dimer_dev(self, d_pool: int, n: int, k: int, chem: Chem, threshold: float,
+                        rows: tuple[int, int], cols: tuple[int, int], d_row_conflicts: int = 0,
+                        d_bitmap: int = 0, d_dg: int = 0, d_tm: int = 0):
+        """Device-pointer call (raw addresses, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        self._check(self.L.msspe_cross_dimer_dev(
+            self.ptr, C.c_void_p(d_pool), n, k, C.byref(chem), C.c_float(threshold),
+            rows[0], rows[1], cols[0], cols[1], C.c_void_p(d_row_conflicts),
+            C.c_void_p(d_bitmap), C.c_void_p(d_dg), C.c_void_p(d_tm)))
+
+    def last_overflow_pairs(self) -> int:
+        v = C.c_uint64()
+        self._check(self.L.msspe_last_overflow_pairs(self.ptr, C.byref(v)))
+        return int(v.value)
+
+    # ---- stage B ---------------------------------------------------------------------------
+    def oligo_stats(self, pool, chem: Chem | None = None):
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.primer3()
+        out = {name: np.empty(n) for name in ("tm", "gc", "self_any", "self_end", "hairpin")}
+        self._check(self.L.msspe_oligo_stats(self.ptr, buf, n, k, C.byref(chem),
+                                             *[out[x].ctypes.data for x in out]))
+        return out
+
+    # ---- stage A ---------------------------------------------------------------------------
+    def kmer_candidates(self, seqs: np.ndarray, opt: KmerOpt, direction: int,
+                        device_ptr: int | None = None, n_seq: int | None = None,
+                        seq_len: int | None = None):
+        """seqs: uint8 (n_seq, L) host array (or pass device_ptr + shape).  Returns (words, freqs)."""
+        cap = max(1, opt.max_iterations)
+        words = np.zeros(cap, dtype=np.uint64)
+        freqs = np.zeros(cap, dtype=np.uint32)
+        n_out = C.c_int(0)
+        if device_ptr is None:
+            a = np.ascontiguousarray(seqs, dtype=np.uint8)
+            n_seq, seq_len = a.shape
+            self._check(self.L.msspe_kmer_candidates(
+                self.ptr, a.ctypes.data, n_seq, seq_len, C.byref(opt), direction,
+                words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
+        else:
+            self._check(self.L.msspe_kmer_candidates_dev(
+                self.ptr, C.c_void_p(device_ptr), n_seq, seq_len, C.byref(opt), direction,
+                words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
+        m = n_out.value
+        return [unpack_oligo(w, opt.kmer_size) for w in words[:m]], freqs[:m].copy()

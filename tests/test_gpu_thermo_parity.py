@@ -1,0 +1,123 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the golden vectors.
+
+Bar: bit-exact doubles for dS/dH/dG/t (both sides evaluate the same IEEE-754 operations in the
+same order, no FMA), identical conflict decisions, identical counts/bitmaps.
+"""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import msspe_amd
+    e = msspe_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def m():
+    import msspe_amd
+    return msspe_amd
+
+
+def bitmap_to_bool(bm, n):
+    bits = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")
+    return bits[:, :n].astype(bool)
+
+
+def check_pool(eng, m, oracle, oracle_tables, pool, chem_kw=None, threshold=-9000.0):
+    chem_kw = chem_kw or {}
+    chem = m.Chem.ntthal(**chem_kw)
+    oargs = oracle.ntthal_args(**{k: v for k, v in chem_kw.items()})
+    out = eng.cross_dimer(pool, chem, threshold, want_dg=True, want_tm=True)
+    cnt, dg, cf, tt = oracle.pool_pairs(oracle_tables, pool, oargs, threshold, want_t=True)
+    n = len(pool)
+    np.testing.assert_array_equal(out["dg"], dg)
+    np.testing.assert_array_equal(out["tm"], tt)
+    got = bitmap_to_bool(out["bitmap"], n)
+    np.testing.assert_array_equal(got, cf.astype(bool))
+    np.testing.assert_array_equal(out["row_conflicts"], cf.sum(1).astype(np.uint32))
+    return out, cnt
+
+
+def test_dimer_goldens_through_the_c_abi(eng, m, golden_dir):
+    """od-msspe/src/delta_g.rs:196-230 via msspe_cross_dimer."""
+    g = json.loads((golden_dir / "ntthal_dimer.json").read_text())
+    for v in g["vectors"]:
+        pool = [v["oligo1"], v["oligo2"]]
+        out = eng.cross_dimer(pool, m.Chem.ntthal(temp_c=v["temp_c"]), 100000.0, want_tm=True)
+        assert "%g" % out["dg"][0, 1] == v["dG"], v["id"]
+        assert "%g" % out["tm"][0, 1] == v["t"], v["id"]
+        assert out["row_conflicts"].tolist() == [2, 2]      # threshold 100000 keeps every pair
+
+
+def test_random_pool_bit_exact(eng, m, oracle, oracle_tables):
+    pool = m.synth.pool_strings(m.synth.random_pool(160, 13))
+    check_pool(eng, m, oracle, oracle_tables, pool)
+
+
+def test_chemistry_and_threshold_variants(eng, m, oracle, oracle_tables):
+    pool = m.synth.pool_strings(m.synth.random_pool(48, 13, seed=5))
+    check_pool(eng, m, oracle, oracle_tables, pool, dict(temp_c=37.0), -2000.0)
+    check_pool(eng, m, oracle, oracle_tables, pool, dict(mv=100.0, dv=0.0, dntp=0.0, dna_conc=50.0), -1000.0)
+    check_pool(eng, m, oracle, oracle_tables, pool, dict(dv=1.5, dntp=0.6), -3000.0)
+
+
+def test_edge_pools(eng, m, oracle, oracle_tables):
+    """No-structure pairs, maximal DP tables (poly-A x poly-T: 169 cells), homopolymers, repeats."""
+    pool = ["A" * 13, "T" * 13, "C" * 13, "G" * 13, "ACACACACACACA", "TGTGTGTGTGTGT",
+            "AAAAAAATTTTTT", "GGGGGGGCCCCCC", "AGCCCGTGTAAAC", "GTTTACACGGGCT", "ATATATATATATA"]
+    out, _ = check_pool(eng, m, oracle, oracle_tables, pool)
+    assert np.isinf(out["dg"][0, 0]) and out["tm"][0, 0] == 0.0          # poly-A vs poly-A
+    assert np.isfinite(out["dg"][0, 1])
+
+
+@pytest.mark.parametrize("k", [6, 8, 12, 16, 20, 27])
+def test_other_oligo_lengths(eng, m, oracle, oracle_tables, k):
+    pool = m.synth.pool_strings(m.synth.random_pool(24 if k <= 16 else 10, k, seed=100 + k))
+    if k % 2 == 0:   # both-self-complementary pairs use the symmetric concentration term
+        half = pool[0][:k // 2]
+        pal = half + oracle.reverse_complement(half)
+        pool += [pal, ("GC" * k)[:k]]
+    check_pool(eng, m, oracle, oracle_tables, pool)
+
+
+def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
+    """primer3_core view (od-msspe/src/primer.rs:143-166): Tm, GC%, SELF_ANY/END, HAIRPIN."""
+    pool = m.synth.pool_strings(m.synth.random_pool(300, 13, seed=9))
+    pool += ["AGCCCGTGTAAAC", "ACGTGAAAACGTA", "GCGCTTTTGCGCA", "GGGGCCCTTTGGG", "ATATATATATATA",
+             "GGGGGGGCCCCCC", "AAAAAAAAAAAAA", "CCCGGGAAACCCG"]
+    got = eng.oligo_stats(pool)
+    ref = oracle.check_primers(oracle_tables, pool)
+    for a, b in (("tm", "tm"), ("gc", "gc"), ("self_any", "self_any_th"),
+                 ("self_end", "self_end_th"), ("hairpin", "hairpin_th")):
+        np.testing.assert_array_equal(got[a], ref[b], err_msg=a)
+    g = json.loads((golden_dir / "primer3_check_primers.json").read_text())["check_primers"][0]
+    i = pool.index(g["primer"])
+    assert m.round_fixed_f32(got["tm"][i], 3) == np.float32(g["tm"])
+    assert m.round_fixed_f32(got["gc"][i], 3) == np.float32(g["gc"])
+    assert got["self_any"][i] == 0.0 and got["self_end"][i] == 0.0 and got["hairpin"][i] == 0.0
+    assert (got["hairpin"] > 0).sum() >= 3
+
+
+def test_oligo_stats_longer_oligos(eng, m, oracle, oracle_tables):
+    pool = m.synth.pool_strings(m.synth.random_pool(40, 20, seed=21)) + ["GGGGCCCTTTTGGGCCCCAA"]
+    got = eng.oligo_stats(pool)
+    ref = oracle.check_primers(oracle_tables, pool)
+    for a, b in (("tm", "tm"), ("self_any", "self_any_th"), ("self_end", "self_end_th"),
+                 ("hairpin", "hairpin_th")):
+        np.testing.assert_array_equal(got[a], ref[b], err_msg=a)
+
+
+def test_argument_errors(eng, m):
+    with pytest.raises(m.MsspeError) as e:
+        eng.cross_dimer(["ACGTNCGTACGTA"])
+    assert e.value.code == 1
+    with pytest.raises(m.MsspeError):
+        eng.cross_dimer(["A"])          # k = 1 unsupported
+    assert eng.cross_dimer([])["row_conflicts"].size == 0
