@@ -32,6 +32,8 @@ struct ChemEntry {
     float threshold;
     ThalConsts c[2];
     PairTables *d_pt = nullptr;   // 2 entries: ordinary, both self-complementary
+    FastTables *d_ft = nullptr;   // tables of the tuned all-pairs kernel (ordinary pairs)
+    bool fast_ok = false;
 };
 
 constexpr long kChunkPairs = 1L << 24;       // pairs per fast launch == overflow-list capacity
@@ -48,8 +50,9 @@ struct msspe_ctx {
     std::vector<ChemEntry> chem_cache;
     double *wsS = nullptr, *wsH = nullptr;
     size_t ws_cells = 0;
-    uint2 *ovf_list = nullptr;
-    uint32_t *ovf_count = nullptr;     // [0] running counter, [1] accumulated total
+    uint2 *ovf_list = nullptr;         // pairs the main kernel could not hold
+    uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
+    uint32_t *ovf_count = nullptr;     // [0] first-stage counter, [1] second-stage counter
     uint64_t *d_ovf_total = nullptr;
     std::string err;
     KmerStage kmer;
@@ -115,6 +118,12 @@ int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntr
     }
     HIP_TRY(ctx, hipMalloc((void **)&e.d_pt, sizeof host_pt));
     HIP_TRY(ctx, hipMemcpy(e.d_pt, host_pt, sizeof host_pt, hipMemcpyHostToDevice));
+    {
+        auto ft = std::make_unique<FastTables>();
+        e.fast_ok = build_fast_tables(ctx->host_tb, host_pt[0], pairs_fast_max_k(), *ft);
+        HIP_TRY(ctx, hipMalloc((void **)&e.d_ft, sizeof(FastTables)));
+        HIP_TRY(ctx, hipMemcpy(e.d_ft, ft.get(), sizeof(FastTables), hipMemcpyHostToDevice));
+    }
     ctx->chem_cache.push_back(e);
     *out = &ctx->chem_cache.back();
     return MSSPE_OK;
@@ -138,6 +147,7 @@ int ensure_overflow(msspe_ctx *ctx)
 {
     if (ctx->ovf_list) return MSSPE_OK;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)kChunkPairs));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)kChunkPairs));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
@@ -222,10 +232,14 @@ void msspe_destroy(msspe_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         ctx->kmer.release();
         for (auto &e : ctx->chem_cache)
+        {
             if (e.d_pt) (void)hipFree(e.d_pt);
+            if (e.d_ft) (void)hipFree(e.d_ft);
+        }
         if (ctx->wsS) (void)hipFree(ctx->wsS);
         if (ctx->wsH) (void)hipFree(ctx->wsH);
         if (ctx->ovf_list) (void)hipFree(ctx->ovf_list);
+        if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
         if (ctx->ovf_count) (void)hipFree(ctx->ovf_count);
         if (ctx->d_ovf_total) (void)hipFree(ctx->d_ovf_total);
         if (ctx->d_tb) (void)hipFree(ctx->d_tb);
@@ -299,7 +313,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
 
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
-    const bool fast = !use_generic_only() && k <= pairs_fast_max_k();
+    const bool fast = !use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok;
     long rows_per_chunk = kChunkPairs / ncols;
     if (rows_per_chunk < 1) rows_per_chunk = 1;   // a single row longer than the chunk: see below
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
@@ -330,9 +344,9 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             g.wsH = ctx->wsH;
             g.ws_lanes = kGenericLanes;
             if (fast) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, sizeof(uint32_t), ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
                 PairKernelArgs a;
-                a.pt = ce->d_pt;
+                a.ft = ce->d_ft;
                 a.c = ce->c[0];
                 a.pool = d_pool;
                 a.n = n;
@@ -346,8 +360,13 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 a.overflow_count = ctx->ovf_count;
                 a.overflow_cap = (uint32_t)kChunkPairs;
                 HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
-                g.list = ctx->ovf_list;
-                g.list_count = ctx->ovf_count;
+                // second stage: the wide register table over the overflow list
+                a.overflow_list = ctx->ovf_list2;
+                a.overflow_count = ctx->ovf_count + 1;
+                HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
+                // third stage: whatever is left (huge tables, both-self-complementary pairs)
+                g.list = ctx->ovf_list2;
+                g.list_count = ctx->ovf_count + 1;
                 g.n_work = (long)(r_end - r) * (long)(c_end - c0);
                 HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
                 hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream,

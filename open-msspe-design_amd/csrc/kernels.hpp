@@ -5,6 +5,7 @@
 
 #include <cstdint>
 
+#include "fast_tables.hpp"
 #include "nn_params.hpp"
 
 namespace msspe {
@@ -61,7 +62,7 @@ hipError_t launch_oligo_tm(const uint64_t *pool, int n, int k, double dna_conc, 
 // register-resident table are appended to overflow_list (capacity overflow_cap) and must be
 // finished by launch_dimer_generic.
 struct PairKernelArgs {
-    const PairTables *pt;      // device, entry 0
+    const FastTables *ft;      // device
     ThalConsts c;
     const uint64_t *pool;
     int n, k;
@@ -72,6 +73,12 @@ struct PairKernelArgs {
     uint32_t overflow_cap;
 };
 hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
+// Wide instantiation over an explicit pair list (the overflow list of launch_pairs_fast); pairs
+// that still do not fit are appended to a.overflow_list.
+hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
+                             const uint32_t *in_count, hipStream_t stream);
 int pairs_fast_max_k();
+int pairs_fast_main_slots();
+int pairs_fast_wide_slots();
 
 }  // namespace msspe

@@ -6,6 +6,7 @@
 // and its getStack / getStackint2 / getTstack / getTstack2 / getDangle / getLoop / getTriloop /
 // getTetraloop readers, restated from SURVEY.md Appendix C.1.
 #include "nn_params.hpp"
+#include "fast_tables.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -439,6 +440,65 @@ double g_cut(float threshold)
         else hi = mid;
     }
     return from_key(lo);
+}
+
+bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastTables &out)
+{
+    (void)t;
+    std::memset(&out, 0, sizeof out);
+    bool ok = pt.h_is_integral != 0;
+    double min_S = 0.0;     // most negative entropy any single DP step can add
+    auto put = [&](int idx, double S, int32_t H) {
+        out.S[idx] = S;
+        out.H[idx] = H;
+        if (H < kHInf) {
+            if (H % 10 != 0) ok = false;
+            if (S < min_S) min_S = S;
+        }
+    };
+    auto addH = [](int32_t a, int32_t b) -> int32_t { return (a >= kHInf || b >= kHInf) ? kHInf : a + b; };
+    const double atS[4] = {6.9, 0.0, 0.0, 6.9};
+    const int32_t atH[4] = {2200, 0, 0, 2200};
+    for (int z = 0; z < 30; ++z) {
+        for (int po = 0; po < 64; ++po) {
+            // po = a | oa << 2 | ob << 4  ->  PairTables index (a*4 + oa)*4 + ob
+            const int src = ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4);
+            put(FastTables::kLxI + z * 64 + po, pt.loopS[0][z] + pt.ts_S[src],
+                addH(pt.loopH[0][z], pt.ts_H[src]));
+        }
+        for (int a = 0; a < 4; ++a)
+            put(FastTables::kLxB + z * 4 + a, pt.loopS[1][z] + atS[a], addH(pt.loopH[1][z], atH[a]));
+    }
+    for (int ac = 0; ac < 4; ++ac)
+        for (int ap = 0; ap < 4; ++ap) {
+            double S = pt.loopS[1][0] + pt.wc_S[ap * 4 + ac];
+            int32_t H = addH(pt.loopH[1][0], pt.wc_H[ap * 4 + ac]);
+            if (H >= kHInf || H > 0 || S > 0) {   // thal.c: isPositive(H) || isPositive(S) -> reject
+                S = -1.0;
+                H = kHInf;
+            }
+            put(FastTables::kLxB1 + ac * 4 + ap, S, H);
+        }
+    for (int po = 0; po < 64; ++po) {
+        const int src = ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4);
+        put(FastTables::kMM + po, pt.mm_S[src], pt.mm_H[src]);
+        put(FastTables::kTS + po, pt.ts_S[src], pt.ts_H[src]);
+        put(FastTables::kMMc + po, pt.mm_S[po], pt.mm_H[po]);   // cell side: index is already (x*4+y)*4+z
+        put(FastTables::kTSc + po, pt.ts_S[po], pt.ts_H[po]);
+    }
+    for (int a = 0; a < 4; ++a) put(FastTables::kAT + a, atS[a], atH[a]);
+    for (int q = 0; q < 4; ++q) put(FastTables::kZero + q, 0.0, 0);
+    for (int q = 0; q < 100; ++q) {
+        put(FastTables::kEndL + q, pt.endL_S[q], pt.endL_H[q]);
+        put(FastTables::kEndR + q, pt.endR_S[q], pt.endR_H[q]);
+    }
+    for (int q = 0; q < 16; ++q) put(FastTables::kWC + q, pt.wc_S[q], pt.wc_H[q]);
+    // clamp reachability: a path has at most max_k pairs, each step adds >= min_S (two table
+    // terms at most per step for interior loops: bounded by 3 * min_S), plus two end terms
+    if (3.0 * min_S * (max_k + 2) < -2500.0) ok = false;
+    out.usable = ok ? 1 : 0;
+    out.max_k = max_k;
+    return ok;
 }
 
 }  // namespace msspe

@@ -1,7 +1,605 @@
-// thal_pairs.hip -- placeholder for the tuned all-pairs kernel (next milestone).
+// thal_pairs.hip -- the tuned all-pairs cross-dimer kernel (thal ANY for every ordered pair).
+//
+// Replaces the reference's hot loop "format N^2 lines -> ntthal -> parse"
+// (/root/reference/od-msspe/src/delta_g.rs:61-153); one "check" = one ordered pair through Primer3
+// 2.6.1 thal() ANY (fillMatrix / maxTM / calc_bulge_internal / terminal pick / traceback /
+// drawDimer, restated from SURVEY.md Appendix C.3) down to the reference's conflict decision.
+//
+// CDNA4 design
+//   * one lane = one ordered pair; one wave = one primer `a` (row) x 64 consecutive primers `b`;
+//     a 256-thread block covers 4 rows x 64 columns and loops over tiles (persistent grid).
+//   * the DP is SPARSE: only complementary cells (about 42 of 169 for random 13-mers) exist; they
+//     are enumerated per lane in row-major order and numbered 0..n-1 ("slots").
+//   * the per-pair DP table lives in VGPRs, not LDS: slot s keeps S (f64) and a packed word
+//     {H/10, predecessor context, i, j}.  All lanes walk slots in lock-step, so the slot number is
+//     wave-uniform and the register file is indexed through M0 (s_set_gpr_idx / v_mov), which
+//     costs no LDS bandwidth, no bank conflicts and no occupancy for a [slot][lane] LDS image.
+//   * LDS holds only the 2.4k-entry thermodynamic tables (fast_tables.hpp), gathered per lane.
+//   * enthalpies are exact integers (checked on the host) and are summed in int32; entropies are
+//     summed in f64 in Primer3's operation order (file built with -ffp-contract=off), so dS, dH,
+//     dG and t are bit-identical to the CPU oracle and decisions are identical by construction.
+//   * min-dG over predecessors is order independent except for exact ties, which are resolved by
+//     Primer3's visiting order (key = loop size, then row distance).
+//   * the conflict bit of the 64 lanes leaves the wave as one ballot word (bitmap) and one
+//     popcount atomic (per-row conflict count): 0.125 B + 1/16 B of HBM traffic per check.
+// Pairs whose DP has more complementary cells than the register table holds go to an overflow
+// list and are finished by the wide instantiation of this kernel (list mode) or the generic kernel.
+#include "fast_tables.hpp"
 #include "kernels.hpp"
+#include "thal_dense.hpp"
 
 namespace msspe {
-int pairs_fast_max_k() { return 0; }
-hipError_t launch_pairs_fast(const PairKernelArgs &, hipStream_t) { return hipErrorNotSupported; }
+
+namespace {
+
+constexpr int kChunk = 8;
+constexpr int kInterleave = 2;   // predecessor evaluations the scheduler may overlap (register budget)
+
+// The register-resident DP table.  Every access below uses a compile-time slot number (the
+// scans are fully unrolled, the store is a switch), so the arrays dissolve into VGPRs.
+template <int NCH>
+struct Slots {
+    double S[NCH * kChunk];
+    int W[NCH * kChunk];
+};
+
+struct Lds {
+    double S[FastTables::kCount];
+    int H[FastTables::kCount];
+};
+
+struct CellCtx {
+    int im1, jm1;            // 0-based cell coordinates (i-1, j-1)
+    int yTS, yMM, yAT, bB1;  // table indices that depend on the cell only
+    double rS;               // right end term of the cell
+    int rH;
+    int maxloop;
+};
+
+struct Cand {
+    double S;
+    int H;
+    bool ok;       // a valid, finite loop candidate
+    bool isStack;  // predecessor is (i-1, j-1)
+    unsigned key;  // Primer3's visiting order among loop candidates (smaller = earlier)
+    int iim1, jjm1;
+};
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+// Candidate value of the loop (or stack) between predecessor slot (Sp, Wp) and cell c.
+__device__ __forceinline__ Cand make_cand(const Lds &T, const CellCtx &c, double Sp, int Wp)
+{
+    Cand r;
+    r.jjm1 = Wp & 15;
+    r.iim1 = (Wp >> 4) & 15;
+    const int po = (Wp >> 8) & 63;
+    const int Hp = (Wp >> 14) * 10;
+    const int l1 = c.im1 - r.iim1 - 1, l2 = c.jm1 - r.jjm1 - 1, sz = l1 + l2;
+    const bool geom = (l1 >= 0) & (l2 >= 0);
+    const bool isBulge = (l1 == 0) | (l2 == 0);
+    const bool sz1 = sz == 1;
+    const bool is1x1 = (l1 == 1) & (l2 == 1);
+    const int a_p = po & 3;
+    int lx = isBulge ? ((sz1 ? c.bB1 : (FastTables::kLxB - 4) + sz * 4) + a_p)
+                     : ((is1x1 ? FastTables::kMM : (FastTables::kLxI - 64) + sz * 64) + po);
+    const int y = isBulge ? (sz1 ? FastTables::kZero : c.yAT) : (is1x1 ? c.yMM : c.yTS);
+    lx = clampi(lx, 0, FastTables::kCount - 1);
+    const int asym = l1 > l2 ? l1 - l2 : l2 - l1;
+    const double Z = isBulge ? 0.0 : kILAS * (double)asym;
+    r.S = ((T.S[lx] + T.S[y]) + Z) + Sp;
+    r.H = T.H[lx] + T.H[y] + Hp;
+    const bool bad = (r.H >= kHInf / 2) | ((r.H > 0) & (r.S > 0.0));
+    r.isStack = geom & (sz == 0);
+    r.ok = geom & (sz > 0) & (sz <= c.maxloop) & !bad;
+    r.key = (unsigned)(sz * 32 + l1);
+    return r;
+}
+
+struct Best {
+    double G, S;
+    int H;
+    unsigned key;
+};
+
+struct SeqPair {
+    unsigned s1, s2;     // 2 bits per base; s2 = oligo 2 reversed
+    unsigned m2[4];      // spaced masks of s2: bit 2p set iff base p == x
+    int len;
+};
+
+// Bases around cell (im1, jm1) and every table index that depends on the cell only.
+struct CellBases {
+    int a, idxL, idxR, wc, po_c;
+};
+__device__ __forceinline__ CellBases cell_bases(const SeqPair &q, int im1, int jm1, CellCtx &c)
+{
+    CellBases b;
+    const int t1 = 2 * im1, t2 = 2 * jm1;
+    b.a = (q.s1 >> t1) & 3;
+    const int oaL = im1 > 0 ? (int)((q.s1 >> (t1 - 2)) & 3) : 4;
+    const int oaR = im1 < q.len - 1 ? (int)((q.s1 >> (t1 + 2)) & 3) : 4;
+    const int obL = jm1 > 0 ? (int)((q.s2 >> (t2 - 2)) & 3) : 4;
+    const int obR = jm1 < q.len - 1 ? (int)((q.s2 >> (t2 + 2)) & 3) : 4;
+    b.idxL = FastTables::kEndL + b.a * 25 + oaL * 5 + obL;
+    b.idxR = FastTables::kEndR + b.a * 25 + oaR * 5 + obR;
+    const int ci = (((3 - b.a) * 4 + (obL & 3)) * 4 + (oaL & 3)) & 63;
+    b.wc = FastTables::kWC + (oaL & 3) * 4 + b.a;
+    b.po_c = b.a | ((oaR & 3) << 2) | ((obR & 3) << 4);
+    c.im1 = im1;
+    c.jm1 = jm1;
+    c.yTS = FastTables::kTSc + ci;
+    c.yMM = FastTables::kMMc + ci;
+    c.yAT = FastTables::kAT + b.a;
+    c.bB1 = FastTables::kLxB1 + b.a * 4;
+    return b;
+}
+
+// ---- register-table access: slot numbers are compile-time constants ---------------------------
+
+// Fill: one predecessor slot against cell c.  `on` masks slots that are not computed yet.
+__device__ __forceinline__ void fill_step(const Lds &T, const CellCtx &c, double Sp, int Wp, bool on,
+                                          Best &best, double &stS, int &stH, bool &stHave)
+{
+    const Cand k = make_cand(T, c, Sp, Wp);
+    const double G1 = (double)(k.H + c.rH) - kT37 * (k.S + c.rS);
+    const bool better = on & k.ok & ((G1 < best.G) | ((G1 == best.G) & (k.key < best.key)));
+    best.G = better ? G1 : best.G;
+    best.S = better ? k.S : best.S;
+    best.H = better ? k.H : best.H;
+    best.key = better ? k.key : best.key;
+    const bool st = on & k.isStack;
+    stS = st ? Sp : stS;
+    stH = st ? (Wp >> 14) * 10 : stH;
+    stHave = stHave | st;
+}
+
+struct TraceHit {
+    unsigned key;
+    double S;
+    int H, im1, jm1, slot;
+};
+
+// Traceback: does predecessor slot p reproduce the current cell's value?
+__device__ __forceinline__ void trace_step(const Lds &T, const CellCtx &c, double Sp, int Wp, int p,
+                                           double curS, int curH, int curSlot, double wcS, int wcH,
+                                           TraceHit &h)
+{
+    const Cand k = make_cand(T, c, Sp, Wp);
+    const int Hp = (Wp >> 14) * 10;
+    const double candS = k.isStack ? wcS + Sp : k.S;
+    const int candH = k.isStack ? wcH + Hp : k.H;
+    const unsigned key = k.isStack ? 0u : k.key;
+    const bool hit = (p < curSlot) & (k.ok | k.isStack) & (candH == curH) &
+                     (fabs(curS - candS) < 1e-5) & (key < h.key);
+    h.key = hit ? key : h.key;
+    h.S = hit ? Sp : h.S;
+    h.H = hit ? Hp : h.H;
+    h.im1 = hit ? k.iim1 : h.im1;
+    h.jm1 = hit ? k.jjm1 : h.jm1;
+    h.slot = hit ? p : h.slot;
+}
+
+template <int NCH, int PC = 0>
+__device__ __forceinline__ void scan_fill_all(const Slots<NCH> &st, int upto, const Lds &T,
+                                              const CellCtx &c, Best &best, double &stS, int &stH,
+                                              bool &stHave)
+{
+    if constexpr (PC < NCH) {
+        if (PC * kChunk < upto) {   // wave-uniform
+            asm volatile("; fill chunk" ::: "memory");   // keep this a real branch (no if-conversion)
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                constexpr int base = PC * kChunk;
+                fill_step(T, c, st.S[base + q], st.W[base + q], base + q < upto, best, stS, stH, stHave);
+                if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            scan_fill_all<NCH, PC + 1>(st, upto, T, c, best, stS, stH, stHave);
+        }
+    }
+}
+
+template <int NCH, int PC = 0>
+__device__ __forceinline__ void scan_trace_all(const Slots<NCH> &st, int upto, const Lds &T,
+                                               const CellCtx &c, double curS, int curH, int curSlot,
+                                               double wcS, int wcH, TraceHit &h)
+{
+    if constexpr (PC < NCH) {
+        if (PC * kChunk < upto) {   // wave-uniform
+            asm volatile("; trace chunk" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                constexpr int base = PC * kChunk;
+                trace_step(T, c, st.S[base + q], st.W[base + q], base + q, curS, curH, curSlot, wcS,
+                           wcH, h);
+                if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            scan_trace_all<NCH, PC + 1>(st, upto, T, c, curS, curH, curSlot, wcS, wcH, h);
+        }
+    }
+}
+
+template <int NCH, int P = 0>
+__device__ __forceinline__ void store_elem(Slots<NCH> &st, int slot, double S, int W)
+{
+    // binary descent over compile-time slot numbers (slot is wave-uniform)
+    if constexpr (P < NCH * kChunk) {
+        if (slot == P) {
+            st.S[P] = S;
+            st.W[P] = W;
+        } else {
+            store_elem<NCH, P + 1>(st, slot, S, W);
+        }
+    }
+}
+
+template <int NCH, int PC = 0>
+__device__ __forceinline__ void store_slot(Slots<NCH> &st, int slot, double S, int W)
+{
+    if constexpr (PC < NCH) {
+        if (slot < (PC + 1) * kChunk) {
+            switch (slot - PC * kChunk) {
+            case 0: st.S[PC * kChunk + 0] = S; st.W[PC * kChunk + 0] = W; break;
+            case 1: st.S[PC * kChunk + 1] = S; st.W[PC * kChunk + 1] = W; break;
+            case 2: st.S[PC * kChunk + 2] = S; st.W[PC * kChunk + 2] = W; break;
+            case 3: st.S[PC * kChunk + 3] = S; st.W[PC * kChunk + 3] = W; break;
+            case 4: st.S[PC * kChunk + 4] = S; st.W[PC * kChunk + 4] = W; break;
+            case 5: st.S[PC * kChunk + 5] = S; st.W[PC * kChunk + 5] = W; break;
+            case 6: st.S[PC * kChunk + 6] = S; st.W[PC * kChunk + 6] = W; break;
+            default: st.S[PC * kChunk + 7] = S; st.W[PC * kChunk + 7] = W; break;
+            }
+        } else {
+            store_slot<NCH, PC + 1>(st, slot, S, W);
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ unsigned spaced_mask(unsigned s, int base, unsigned lenmask)
+{
+    // bit 2p set iff the 2-bit field p of s equals base
+    const unsigned x = s ^ (unsigned)(base * 0x55555555u);
+    return ~(x | (x >> 1)) & 0x55555555u & lenmask;
+}
+
+__device__ __forceinline__ unsigned reverse2(unsigned s, int len)
+{
+    // reverse the order of the len 2-bit fields
+    unsigned r = __brev(s);                                   // bit reversal
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);  // restore bit order inside fields
+    return r >> (32 - 2 * len);
+}
+
+struct PairResult {
+    double dG, t;
+    bool none, conflict;
+};
+
+// The whole thal ANY computation for the lane's pair.  n_cells == 0 means "lane idle".
+template <int NCH>
+__device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K, const SeqPair &q,
+                                               unsigned rowmask, int n_cells, int nmax)
+{
+    Slots<NCH> st;
+#pragma unroll
+    for (int x = 0; x < NCH * kChunk; ++x) {
+        st.S[x] = 0.0;
+        st.W[x] = 0;
+    }
+    CellCtx c;
+    c.maxloop = K.max_loop;
+    c.rS = 0.0;
+    c.rH = 0;
+    c.im1 = c.jm1 = 0;
+    c.yTS = c.yMM = c.yAT = c.bB1 = 0;
+    unsigned Rrem = rowmask, mrem = 0;
+    int im1 = 0, jm1 = 0;
+    // terminal pick (thal.c thal(): strict minimum of the nudged dG, first in row-major order)
+    double pickG = INFINITY, pickS = 0.0, pickRS = 0.0;
+    int pickH = 0, pickRH = 0, pickI = 0, pickJ = 0, pickSlot = 0;
+
+    for (int slot_ = 0; slot_ < nmax; ++slot_) {
+        const int slot = __builtin_amdgcn_readfirstlane(slot_);
+        const bool active = slot < n_cells;
+        // ---- next complementary cell in row-major order
+        const bool newrow = mrem == 0;
+        const int t = __ffs((int)Rrem) - 1;
+        const int a_new = (q.s1 >> (t & 31)) & 3;
+        const unsigned m_new = a_new == 0 ? q.m2[3] : a_new == 1 ? q.m2[2] : a_new == 2 ? q.m2[1] : q.m2[0];
+        im1 = newrow ? (t >> 1) : im1;
+        Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
+        mrem = newrow ? m_new : mrem;
+        jm1 = (__ffs((int)mrem) - 1) >> 1;
+        mrem &= mrem - 1;
+        im1 &= 15;
+        jm1 &= 15;
+        const CellBases b = cell_bases(q, im1, jm1, c);
+        const double leftS = T.S[b.idxL];
+        const int leftH = T.H[b.idxL];
+        c.rS = T.S[b.idxR];
+        c.rH = T.H[b.idxR];
+        // ---- all earlier slots as predecessors
+        Best best;
+        best.G = INFINITY;
+        best.S = 0.0;
+        best.H = 0;
+        best.key = 0xffffffffu;
+        double stS = 0.0;
+        int stH = 0;
+        bool stHave = false;
+        scan_fill_all<NCH>(st, slot, T, c, best, stS, stH, stHave);
+        // ---- thal.c maxTM(): helix extension if it raises Tm
+        double S0 = leftS;
+        int H0 = leftH;
+        if (stHave) {
+            const double T0 = (double)(H0 + 200 + c.rH) / (((S0 + K.init_S) + c.rS) + K.RC);
+            const double S1 = stS + T.S[b.wc];
+            const int H1 = stH + T.H[b.wc];
+            const double T1 = (double)(H1 + 200 + c.rH) / (((S1 + K.init_S) + c.rS) + K.RC);
+            if (T1 > T0) {
+                S0 = S1;
+                H0 = H1;
+            }
+        }
+        // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
+        const double G2 = (double)(H0 + c.rH) - kT37 * (S0 + c.rS);
+        if (best.G < G2) {
+            S0 = best.S;
+            H0 = best.H;
+        }
+        // ---- terminal pick
+        const double rSn = c.rS + kTiny, rHn = (double)c.rH + kTiny;
+        const double Gt = (((double)H0 + rHn) + K.init_H) - kT37 * ((S0 + rSn) + K.init_S);
+        const bool pick = active & (Gt < pickG);
+        pickG = pick ? Gt : pickG;
+        pickS = pick ? S0 : pickS;
+        pickH = pick ? H0 : pickH;
+        pickRS = pick ? c.rS : pickRS;
+        pickRH = pick ? c.rH : pickRH;
+        pickI = pick ? im1 : pickI;
+        pickJ = pick ? jm1 : pickJ;
+        pickSlot = pick ? slot : pickSlot;
+        // ---- publish the cell (idle lanes write a slot nobody reads)
+        store_slot<NCH>(st, slot, S0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
+    }
+
+    PairResult r;
+    r.none = n_cells == 0;
+    r.dG = INFINITY;
+    r.t = 0.0;
+    r.conflict = false;
+
+    // ---- thal.c traceback(): count the base pairs of the optimal structure
+    double curS = pickS;
+    int curH = pickH, curI = pickI, curJ = pickJ, curSlot = pickSlot, P = 1;
+    bool done = r.none;
+    for (int step = 0; step < 2 * 16 + 2; ++step) {
+        if (__builtin_amdgcn_readfirstlane((int)__all(done))) break;
+        const CellBases b = cell_bases(q, curI, curJ, c);
+        const double leftS = T.S[b.idxL];
+        const int leftH = T.H[b.idxL];
+        done = done | ((leftH == curH) & (fabs(curS - leftS) < 1e-5));
+        const int bound = wave_max(done ? 0 : curSlot);
+        TraceHit h;
+        h.key = 0xffffffffu;
+        h.S = 0.0;
+        h.H = h.im1 = h.jm1 = h.slot = 0;
+        scan_trace_all<NCH>(st, bound, T, c, curS, curH, curSlot, T.S[b.wc], T.H[b.wc], h);
+        const bool moved = !done & (h.key != 0xffffffffu);
+        done = done | !moved;
+        curS = moved ? h.S : curS;
+        curH = moved ? h.H : curH;
+        curI = moved ? h.im1 : curI;
+        curJ = moved ? h.jm1 : curJ;
+        curSlot = moved ? h.slot : curSlot;
+        P += moved ? 1 : 0;
+    }
+    // ---- thal.c drawDimer(): totals
+    const double dH = (double)(pickH + pickRH + 200);
+    const double dS = (pickS + pickRS) + K.init_S;
+    const int N = P - 1;
+    const double t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
+    const double G = dH - (K.temp_k * (dS + (N * K.salt)));
+    if (!r.none) {
+        r.dG = G;
+        r.t = t;
+        r.conflict = G <= K.g_cut;
+    }
+    return r;
+}
+
+__device__ __forceinline__ int setup_pair(uint64_t pa, uint64_t pb, int k, SeqPair &q,
+                                          unsigned &rowmask)
+{
+    const unsigned lenmask = k == 16 ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+    q.len = k;
+    q.s1 = (unsigned)pa & lenmask;
+    q.s2 = reverse2((unsigned)pb & lenmask, k);
+    unsigned m1[4];
+    int n_cells = 0;
+    rowmask = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        m1[x] = spaced_mask(q.s1, x, lenmask);
+        q.m2[x] = spaced_mask(q.s2, x, lenmask);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        n_cells += __popc(m1[x]) * __popc(q.m2[3 - x]);
+        rowmask |= q.m2[3 - x] ? m1[x] : 0u;
+    }
+    return n_cells;
+}
+
+__device__ __forceinline__ void load_tables(Lds &T, const FastTables *ft)
+{
+    for (int e = threadIdx.x; e < FastTables::kCount; e += blockDim.x) {
+        T.S[e] = ft->S[e];
+        T.H[e] = ft->H[e];
+    }
+    __syncthreads();
+}
+
+struct FastArgs {
+    const FastTables *ft;
+    ThalConsts c;
+    const uint64_t *pool;
+    int k;
+    int row0, row1, col0, col1;   // tile range of this launch (matrix mode)
+    PairSinks sinks;
+    uint2 *ovf_list;
+    uint32_t *ovf_count;
+    uint32_t ovf_cap;
+    const uint2 *in_list;         // list mode: explicit pairs
+    const uint32_t *in_count;
+};
+
+// Matrix mode: wave = one row x 64 columns.
+template <int NCH>
+__global__ void __launch_bounds__(256, 2) k_pairs_fast(FastArgs a)
+{
+    __shared__ Lds T;
+    load_tables(T, a.ft);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncolg = (a.col1 - a.col0 + 63) >> 6;
+    const int nrowg = (a.row1 - a.row0 + 3) >> 2;
+    const long tiles = (long)ncolg * nrowg;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int rg = (int)(tile / ncolg), cg = (int)(tile % ncolg);
+        const int row = a.row0 + rg * 4 + wave;
+        const int col = a.col0 + cg * 64 + lane;
+        if (row >= a.row1) continue;   // wave-uniform
+        const bool inside = col < a.col1;
+        const uint64_t pa = a.pool[row];
+        const uint64_t pb = a.pool[inside ? col : a.col0];
+        SeqPair q;
+        unsigned rowmask;
+        int n_cells = setup_pair(pa, pb, a.k, q, rowmask);
+        const bool sym = self_complementary(pa, a.k) && self_complementary(pb, a.k);
+        const bool spill = inside & ((n_cells > NCH * kChunk) | sym);
+        if (spill) {
+            const uint32_t at = atomicAdd(a.ovf_count, 1u);
+            if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
+        }
+        if (!inside | spill) n_cells = 0;
+        const int nmax = wave_max(n_cells);
+        const PairResult r = run_pair<NCH>(T, a.c, q, rowmask, n_cells, nmax);
+        // ---- sinks
+        const bool live = inside & !spill;
+        const unsigned long long bits = __ballot(live & r.conflict);
+        const size_t orow = (size_t)(row - a.sinks.row0);
+        const size_t ocol = (size_t)(col - a.sinks.col0);
+        if (lane == 0) {
+            if (a.sinks.bitmap) a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)] = bits;
+            if (a.sinks.row_conflicts && bits) atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+        }
+        if (live) {
+            if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
+            if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
+        }
+    }
+}
+
+// List mode: lane = one explicit pair (the overflow list of the matrix kernel).
+template <int NCH>
+__global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
+{
+    __shared__ Lds T;
+    load_tables(T, a.ft);
+    const long n_work = (long)min(*a.in_count, a.ovf_cap);
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long rounds = (n_work + stride - 1) / stride;
+    for (long rd = 0; rd < rounds; ++rd) {
+        const long w = first + rd * stride;
+        const bool inside = w < n_work;
+        const uint2 pr = a.in_list[inside ? w : 0];
+        const uint64_t pa = a.pool[pr.x], pb = a.pool[pr.y];
+        SeqPair q;
+        unsigned rowmask;
+        int n_cells = setup_pair(pa, pb, a.k, q, rowmask);
+        const bool sym = self_complementary(pa, a.k) && self_complementary(pb, a.k);
+        const bool spill = inside & ((n_cells > NCH * kChunk) | sym);
+        if (spill) {
+            const uint32_t at = atomicAdd(a.ovf_count, 1u);
+            if (at < a.ovf_cap) a.ovf_list[at] = pr;
+        }
+        if (!inside | spill) n_cells = 0;
+        const int nmax = wave_max(n_cells);
+        const PairResult r = run_pair<NCH>(T, a.c, q, rowmask, n_cells, nmax);
+        if (inside & !spill) {
+            const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
+            const size_t ocol = (size_t)((int)pr.y - a.sinks.col0);
+            if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
+            if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
+            if (r.conflict) {
+                if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[pr.x], 1u);
+                if (a.sinks.bitmap)
+                    atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
+                             1ull << (ocol & 63));
+            }
+        }
+    }
+}
+
+constexpr int kNchMain = 7;    // 56 slots: covers 98.8 % of random 13-mer pairs at 2 waves / SIMD
+constexpr int kNchWide = 16;   // 128 slots: 1 wave / SIMD, for the overflow list
+
+}  // namespace
+
+int pairs_fast_max_k() { return 16; }
+int pairs_fast_main_slots() { return kNchMain * kChunk; }
+int pairs_fast_wide_slots() { return kNchWide * kChunk; }
+
+hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
+{
+    FastArgs f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    const long tiles = (long)((a.col1 - a.col0 + 63) / 64) * (long)((a.row1 - a.row0 + 3) / 4);
+    if (tiles <= 0) return hipSuccess;
+    const int grid = (int)(tiles < 256L * 8 ? tiles : 256L * 8);
+    hipLaunchKernelGGL(k_pairs_fast<kNchMain>, dim3(grid), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
+                             const uint32_t *in_count, hipStream_t stream)
+{
+    FastArgs f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = in_list;
+    f.in_count = in_count;
+    hipLaunchKernelGGL(k_pairs_list<kNchWide>, dim3(256 * 2), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+
 }  // namespace msspe

@@ -61,13 +61,13 @@ long orc_pool_pairs(const orc_tables *t, const char *pool, int n, int k, int row
 /* Averaged instrumentation over all ordered pairs of a pool (measured op count). */
 int orc_pool_op_stats(const orc_tables *t, const char *pool, int n, int k,
                       const orc_thal_args *args, double *mean_cells, double *mean_loop_evals,
-                      double *mean_end_evals, double *mean_f64_ops);
+                      double *mean_end_evals, double *mean_f64_ops, double *mean_end_ops);
 
 int orc_pool_op_stats(const orc_tables *t, const char *pool, int n, int k,
                       const orc_thal_args *args, double *mean_cells, double *mean_loop_evals,
-                      double *mean_end_evals, double *mean_f64_ops)
+                      double *mean_end_evals, double *mean_f64_ops, double *mean_end_ops)
 {
-    double c = 0, l = 0, e = 0, f = 0;
+    double c = 0, l = 0, e = 0, f = 0, g = 0;
     char a[ORC_MAX_OLIGO], b[ORC_MAX_OLIGO];
     for (int i = 0; i < n; i++) {
         memcpy(a, pool + (size_t)i * k, (size_t)k);
@@ -81,6 +81,7 @@ int orc_pool_op_stats(const orc_tables *t, const char *pool, int n, int k,
             l += (double)r.n_loop_evals;
             e += (double)r.n_end_evals;
             f += (double)r.n_f64_ops;
+            g += (double)r.n_end_ops;
         }
     }
     const double nn = (double)n * (double)n;
@@ -88,6 +89,7 @@ int orc_pool_op_stats(const orc_tables *t, const char *pool, int n, int k,
     *mean_loop_evals = l / nn;
     *mean_end_evals = e / nn;
     *mean_f64_ops = f / nn;
+    *mean_end_ops = g / nn;
     return 0;
 }
 

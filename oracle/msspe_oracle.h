@@ -93,6 +93,7 @@ typedef struct {
     long n_loop_evals;    /* bulge/interior candidates evaluated in the fill          */
     long n_end_evals;     /* LSH/RSH evaluations                                      */
     long n_f64_ops;       /* double add/sub/mul/div/compare executed, fill+pick+traceback */
+    long n_end_ops;       /* the part of n_f64_ops spent inside LSH/RSH evaluations          */
 } orc_thal_result;
 
 void orc_thal_default_args(orc_thal_args *a);  /* ntthal/od-msspe defaults: 50/3/0/250, 25 C */

@@ -31,7 +31,7 @@ class ThalResult(C.Structure):
                 ("ps1", C.c_int * MAX_OLIGO), ("ps2", C.c_int * MAX_OLIGO),
                 ("bp", C.c_int * MAX_OLIGO),
                 ("n_cells", C.c_long), ("n_loop_evals", C.c_long), ("n_end_evals", C.c_long),
-                ("n_f64_ops", C.c_long)]
+                ("n_f64_ops", C.c_long), ("n_end_ops", C.c_long)]
 
 
 class PrimerInfo(C.Structure):
@@ -92,7 +92,7 @@ def lib() -> C.CDLL:
                                      C.POINTER(ThalArgs), C.c_float, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_pool_op_stats.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int,
-                                        C.POINTER(ThalArgs)] + [C.POINTER(C.c_double)] * 4
+                                        C.POINTER(ThalArgs)] + [C.POINTER(C.c_double)] * 5
         L.orc_reverse_complement.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
         L.orc_find_kmers.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_int]
         L.orc_partition_count.argtypes = [C.c_size_t, C.c_int, C.c_int]
@@ -220,10 +220,15 @@ def pool_pairs(tables: Tables, pool: list[str] | np.ndarray, args: ThalArgs | No
 
 def pool_op_stats(tables: Tables, pool: list[str], args: ThalArgs | None = None) -> dict:
     args = args or ntthal_args()
-    v = [C.c_double() for _ in range(4)]
+    v = [C.c_double() for _ in range(5)]
     lib().orc_pool_op_stats(tables.ptr, "".join(pool).encode(), len(pool), len(pool[0]),
                             C.byref(args), *[C.byref(x) for x in v])
-    return dict(zip(["cells", "loop_evals", "end_evals", "f64_ops"], [x.value for x in v]))
+    d = dict(zip(["cells", "loop_evals", "end_evals", "f64_ops", "end_ops"], [x.value for x in v]))
+    # the reference recomputes the state-independent end terms (LSH/RSH) at every use; an
+    # implementation that hoists them needs two evaluations per complementary cell
+    per_end = d["end_ops"] / max(d["end_evals"], 1.0)
+    d["f64_ops_hoisted"] = d["f64_ops"] - d["end_ops"] + 2.0 * d["cells"] * per_end
+    return d
 
 
 def round_g_f32(x: float) -> float:

@@ -38,7 +38,7 @@ typedef struct {
     double S[ORC_MAX_OLIGO + 1][ORC_MAX_OLIGO + 1];
     double H[ORC_MAX_OLIGO + 1][ORC_MAX_OLIGO + 1];
     double init_H, init_S, RC, salt;
-    long ops, n_cells, n_loop, n_end;
+    long ops, n_cells, n_loop, n_end, end_ops;
 } dimer_ctx;
 
 static int code_of(char c)
@@ -85,6 +85,7 @@ static void end_term(dimer_ctx *c, int i, int j, int left, double *outS, double 
 {
     const orc_tables *tb = c->tb;
     const int a = c->s1[i], b = c->s2[j];
+    const long ops_in = c->ops;
     c->n_end++;
     if (!is_pair(a, b)) {
         *outS = -1.0;
@@ -182,6 +183,7 @@ static void end_term(dimer_ctx *c, int i, int j, int left, double *outS, double 
         *outS = S2;
         *outH = H2;
     }
+    c->end_ops += c->ops - ops_in;
 }
 
 /*
@@ -559,6 +561,7 @@ int orc_thal_dimer(const orc_tables *t, const char *oligo1, const char *oligo2, 
     r->n_loop_evals = c->n_loop;
     r->n_end_evals = c->n_end;
     r->n_f64_ops = c->ops;
+    r->n_end_ops = c->end_ops;
     free(c);
     return 0;
 }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Quick GPU timing of the cross-dimer screen at a few pool sizes (development aid)."""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "open-msspe-design_amd"))
+import numpy as np
+import torch
+import msspe_amd as m
+
+
+def main():
+    sizes = [int(x) for x in sys.argv[1:]] or [2048, 8192]
+    eng = m.Engine(0)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    chem = m.Chem.ntthal()
+    for n in sizes:
+        pool = m.pack_oligos(m.synth.random_pool(n, 13))
+        d_pool = torch.from_numpy(pool.view(np.int64)).cuda()
+        words = (n + 63) // 64
+        d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_bm = torch.zeros((n, words), dtype=torch.int64, device="cuda")
+        def run():
+            d_rc.zero_()
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, chem, -9000.0, (0, n), (0, n),
+                                d_rc.data_ptr(), d_bm.data_ptr())
+        run()
+        torch.cuda.synchronize()
+        ovf = eng.last_overflow_pairs()
+        t0 = time.time()
+        reps = 2
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / reps
+        print(f"n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
+              f"overflow pairs={ovf} ({100.0*ovf/(n*n):.2f} %)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
