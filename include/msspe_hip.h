@@ -66,9 +66,10 @@ int msspe_create(int device, const char *params_path, msspe_ctx **out);
 void msspe_destroy(msspe_ctx *ctx);
 const char *msspe_last_error(const msspe_ctx *ctx);
 const char *msspe_version(void);
-/* Use the caller's hipStream_t (e.g. PyTorch's current stream) for every later _dev call.
- * NULL = the context's own stream. */
+/* Use the caller's hipStream_t (e.g. PyTorch's current stream) for every later call; NULL is
+ * HIP's default (null) stream.  msspe_reset_stream() returns to the context's own stream. */
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
+int msspe_reset_stream(msspe_ctx *ctx);
 int msspe_synchronize(msspe_ctx *ctx);
 
 /* ---- packing ------------------------------------------------------------------------------ */
@@ -142,6 +143,8 @@ typedef struct {
  * with U->T (od-msspe/src/main.rs:115-118).  direction 0 = head windows as-is, 1 = tail windows
  * reverse-complemented.  Winners are written in selection order: words as packed uint64 and
  * their frequency.  *n_out = number of winners (<= capacity, else MSSPE_ERR_CAPACITY).
+ * words_out / freq_out / n_out are HOST buffers in both variants (at most max_iterations small
+ * records); only the sequences differ (host pointer vs. device pointer).
  */
 int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
                           const msspe_kmer_opt *opt, int direction,

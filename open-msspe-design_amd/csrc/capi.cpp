@@ -253,7 +253,14 @@ const char *msspe_last_error(const msspe_ctx *ctx) { return ctx ? ctx->err.c_str
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return MSSPE_ERR_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream
+    return MSSPE_OK;
+}
+
+int msspe_reset_stream(msspe_ctx *ctx)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    ctx->stream = ctx->own_stream;
     return MSSPE_OK;
 }
 

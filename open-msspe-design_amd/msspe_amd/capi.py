@@ -13,7 +13,8 @@ STATUS = {0: "MSSPE_OK", 1: "MSSPE_ERR_ARG", 2: "MSSPE_ERR_K", 3: "MSSPE_ERR_TAB
 # every symbol include/msspe_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "msspe_chem_ntthal_defaults", "msspe_chem_primer3_defaults", "msspe_create", "msspe_destroy",
-    "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_synchronize",
+    "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
+    "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
     "msspe_last_overflow_pairs", "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
@@ -71,6 +72,7 @@ def load_library() -> C.CDLL:
     L.msspe_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
     L.msspe_destroy.argtypes = [vp]
     L.msspe_set_stream.argtypes = [vp, vp]
+    L.msspe_reset_stream.argtypes = [vp]
     L.msspe_synchronize.argtypes = [vp]
     L.msspe_pack_oligos.argtypes = [C.c_char_p, C.c_int, C.c_int, u64p]
     L.msspe_unpack_oligo.argtypes = [C.c_uint64, C.c_int, C.c_char_p]
@@ -171,7 +173,11 @@ class Engine:
             raise MsspeError(rc, self.L.msspe_last_error(self.ptr).decode())
 
     def set_stream(self, hip_stream: int | None):
+        """Run on the caller's HIP stream (raw handle; 0/None = HIP's default stream)."""
         self._check(self.L.msspe_set_stream(self.ptr, C.c_void_p(hip_stream or 0)))
+
+    def reset_stream(self):
+        self._check(self.L.msspe_reset_stream(self.ptr))
 
     def synchronize(self):
         self._check(self.L.msspe_synchronize(self.ptr))

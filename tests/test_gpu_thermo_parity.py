@@ -121,3 +121,55 @@ def test_argument_errors(eng, m):
     with pytest.raises(m.MsspeError):
         eng.cross_dimer(["A"])          # k = 1 unsupported
     assert eng.cross_dimer([])["row_conflicts"].size == 0
+
+
+def test_counts_and_bitmap_only_path_medium_pool(eng, m, oracle, oracle_tables):
+    """512^2 ordered pairs through the device-pointer entry point without the dense dG output
+    (the configuration bench.py times), on the caller's stream, several tiles per block."""
+    import torch
+    n = 512
+    pool_ascii = m.synth.random_pool(n, 13, seed=77)
+    d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
+    d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_bm = torch.zeros((n, (n + 63) // 64), dtype=torch.int64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for _ in range(2):          # twice: results must not depend on leftovers of the last call
+            d_rc.zero_()
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, m.Chem.ntthal(), -9000.0, (0, n), (0, n),
+                                d_rc.data_ptr(), d_bm.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        eng.reset_stream()
+    cnt, _, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii, want_dg=False)
+    got = bitmap_to_bool(d_bm.cpu().numpy().view(np.uint64), n)
+    np.testing.assert_array_equal(got, cf.astype(bool))
+    np.testing.assert_array_equal(d_rc.cpu().numpy().astype(np.int64), cf.sum(1))
+    assert int(d_rc.sum()) == cnt
+    assert eng.last_overflow_pairs() > 0      # the overflow stages were exercised
+
+
+def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables):
+    """A rectangular block of the pair matrix (what one rank computes in the multi-GPU tiling)."""
+    import torch
+    n = 200
+    pool_ascii = m.synth.random_pool(n, 13, seed=78)
+    d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
+    r0, r1, c0, c1 = 37, 150, 64, 200
+    d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_dg = torch.full((r1 - r0, c1 - c0), 7.0, dtype=torch.float64, device="cuda")
+    d_bm = torch.zeros((r1 - r0, (c1 - c0 + 63) // 64), dtype=torch.int64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, m.Chem.ntthal(), -9000.0, (r0, r1), (c0, c1),
+                            d_rc.data_ptr(), d_bm.data_ptr(), d_dg.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        eng.reset_stream()
+    _, dg, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii)
+    np.testing.assert_array_equal(d_dg.cpu().numpy(), dg[r0:r1, c0:c1])
+    want = np.zeros(n, dtype=np.int64)
+    want[r0:r1] = cf[r0:r1, c0:c1].sum(1)
+    np.testing.assert_array_equal(d_rc.cpu().numpy().astype(np.int64), want)
+    got = bitmap_to_bool(d_bm.cpu().numpy().view(np.uint64), c1 - c0)
+    np.testing.assert_array_equal(got, cf[r0:r1, c0:c1].astype(bool))
