@@ -24,6 +24,8 @@
 //     popcount atomic (per-row conflict count): 0.125 B + 1/16 B of HBM traffic per check.
 // Pairs whose DP has more complementary cells than the register table holds go to an overflow
 // list and are finished by the wide instantiation of this kernel (list mode) or the generic kernel.
+#include <cstdlib>
+
 #include "fast_tables.hpp"
 #include "kernels.hpp"
 #include "thal_dense.hpp"
@@ -180,41 +182,64 @@ __device__ __forceinline__ void trace_step(const Lds &T, const CellCtx &c, doubl
     h.slot = hit ? p : h.slot;
 }
 
-template <int NCH, int PC = 0>
+// Copies chunk `pc` (wave-uniform, dynamic) of the register table into 8 working registers.  The
+// switch keeps every table access compile-time indexed; only the 24 v_mov of one case execute.
+template <int NCH>
+__device__ __forceinline__ void fetch_chunk(const Slots<NCH> &st, int pc, double (&S)[kChunk],
+                                            int (&W)[kChunk])
+{
+#define MSSPE_FETCH(PC)                                                   \
+    case PC:                                                              \
+        if constexpr (PC < NCH) {                                         \
+            _Pragma("unroll") for (int q = 0; q < kChunk; ++q) {          \
+                S[q] = st.S[(PC < NCH ? PC : 0) * kChunk + q];            \
+                W[q] = st.W[(PC < NCH ? PC : 0) * kChunk + q];            \
+            }                                                             \
+        }                                                                 \
+        break;
+    switch (pc) {
+        MSSPE_FETCH(0) MSSPE_FETCH(1) MSSPE_FETCH(2) MSSPE_FETCH(3) MSSPE_FETCH(4) MSSPE_FETCH(5)
+        MSSPE_FETCH(6) MSSPE_FETCH(7) MSSPE_FETCH(8) MSSPE_FETCH(9) MSSPE_FETCH(10) MSSPE_FETCH(11)
+        MSSPE_FETCH(12) MSSPE_FETCH(13) MSSPE_FETCH(14) MSSPE_FETCH(15)
+    default: break;
+    }
+#undef MSSPE_FETCH
+}
+
+template <int NCH>
 __device__ __forceinline__ void scan_fill_all(const Slots<NCH> &st, int upto, const Lds &T,
                                               const CellCtx &c, Best &best, double &stS, int &stH,
                                               bool &stHave)
 {
-    if constexpr (PC < NCH) {
-        if (PC * kChunk < upto) {   // wave-uniform
-            asm volatile("; fill chunk" ::: "memory");   // keep this a real branch (no if-conversion)
+    const int nch = (upto + kChunk - 1) / kChunk;   // wave-uniform
+    for (int pc_ = 0; pc_ < nch; ++pc_) {
+        const int pc = __builtin_amdgcn_readfirstlane(pc_);
+        double S[kChunk];
+        int W[kChunk];
+        fetch_chunk<NCH>(st, pc, S, W);
 #pragma unroll
-            for (int q = 0; q < kChunk; ++q) {
-                constexpr int base = PC * kChunk;
-                fill_step(T, c, st.S[base + q], st.W[base + q], base + q < upto, best, stS, stH, stHave);
-                if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            scan_fill_all<NCH, PC + 1>(st, upto, T, c, best, stS, stH, stHave);
+        for (int q = 0; q < kChunk; ++q) {
+            fill_step(T, c, S[q], W[q], pc * kChunk + q < upto, best, stS, stH, stHave);
+            if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int NCH, int PC = 0>
+template <int NCH>
 __device__ __forceinline__ void scan_trace_all(const Slots<NCH> &st, int upto, const Lds &T,
                                                const CellCtx &c, double curS, int curH, int curSlot,
                                                double wcS, int wcH, TraceHit &h)
 {
-    if constexpr (PC < NCH) {
-        if (PC * kChunk < upto) {   // wave-uniform
-            asm volatile("; trace chunk" ::: "memory");
+    const int nch = (upto + kChunk - 1) / kChunk;   // wave-uniform
+    for (int pc_ = 0; pc_ < nch; ++pc_) {
+        const int pc = __builtin_amdgcn_readfirstlane(pc_);
+        double S[kChunk];
+        int W[kChunk];
+        fetch_chunk<NCH>(st, pc, S, W);
 #pragma unroll
-            for (int q = 0; q < kChunk; ++q) {
-                constexpr int base = PC * kChunk;
-                trace_step(T, c, st.S[base + q], st.W[base + q], base + q, curS, curH, curSlot, wcS,
-                           wcH, h);
-                if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            scan_trace_all<NCH, PC + 1>(st, upto, T, c, curS, curH, curSlot, wcS, wcH, h);
+        for (int q = 0; q < kChunk; ++q) {
+            trace_step(T, c, S[q], W[q], pc * kChunk + q, curS, curH, curSlot, wcS, wcH, h);
+            if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -460,8 +485,8 @@ struct FastArgs {
 };
 
 // Matrix mode: wave = one row x 64 columns.
-template <int NCH>
-__global__ void __launch_bounds__(256, 2) k_pairs_fast(FastArgs a)
+template <int NCH, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
 {
     __shared__ Lds T;
     load_tables(T, a.ft);
@@ -576,7 +601,16 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
     const long tiles = (long)((a.col1 - a.col0 + 63) / 64) * (long)((a.row1 - a.row0 + 3) / 4);
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L * 8 ? tiles : 256L * 8);
-    hipLaunchKernelGGL(k_pairs_fast<kNchMain>, dim3(grid), dim3(256), 0, stream, f);
+    static const int variant = [] {
+        const char *e = getenv("MSSPE_MAIN_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    switch (variant) {
+    case 1: hipLaunchKernelGGL((k_pairs_fast<6, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    case 2: hipLaunchKernelGGL((k_pairs_fast<7, 1>), dim3(grid), dim3(256), 0, stream, f); break;
+    case 3: hipLaunchKernelGGL((k_pairs_fast<5, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    default: hipLaunchKernelGGL((k_pairs_fast<kNchMain, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    }
     return hipGetLastError();
 }
 

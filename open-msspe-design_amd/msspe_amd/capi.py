@@ -60,6 +60,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:                      # PyTorch ships its own HIP runtime; when it is used in the same
+        import torch          # process it must be loaded first so that a single runtime exists
+    except Exception:         # (torch is plumbing here: device buffers, streams, torch.distributed)
+        pass
     p = lib_path()
     if not p.exists():
         raise ImportError(f"{p} is missing: build it with open-msspe-design_amd/build.sh "
