@@ -110,6 +110,12 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
  * DP did not fit the fast kernel's register-resident table. */
 int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
 
+/* Measurement aid: when enabled, every launch of the dominant kernel (the all-pairs kernel) is
+ * bracketed by HIP events on the context's stream; msspe_profile_read() synchronises and returns
+ * the number of launches and their summed device time since the last read. */
+int msspe_profile_enable(msspe_ctx *ctx, int on);
+int msspe_profile_read(msspe_ctx *ctx, uint64_t *launches, double *total_ms);
+
 /* ---- stage B: per-oligo statistics (replaces check_primers -> primer3_core,
  *      od-msspe/src/primer.rs:143-166) ---------------------------------------------------- */
 

@@ -56,6 +56,10 @@ struct msspe_ctx {
     uint64_t *d_ovf_total = nullptr;
     std::string err;
     KmerStage kmer;
+    // optional profiling of the dominant kernel (k_pairs_fast) with HIP events on ctx->stream
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -243,6 +247,10 @@ void msspe_destroy(msspe_ctx *ctx)
         if (ctx->ovf_count) (void)hipFree(ctx->ovf_count);
         if (ctx->d_ovf_total) (void)hipFree(ctx->d_ovf_total);
         if (ctx->d_tb) (void)hipFree(ctx->d_tb);
+        for (auto &ev : ctx->prof_events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
         (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx;
@@ -366,7 +374,18 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 a.overflow_list = ctx->ovf_list;
                 a.overflow_count = ctx->ovf_count;
                 a.overflow_cap = (uint32_t)kChunkPairs;
+                if (ctx->prof_on) {
+                    if (ctx->prof_used == ctx->prof_events.size()) {
+                        hipEvent_t e0, e1;
+                        HIP_TRY(ctx, hipEventCreate(&e0));
+                        HIP_TRY(ctx, hipEventCreate(&e1));
+                        ctx->prof_events.emplace_back(e0, e1);
+                    }
+                    HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
+                }
                 HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
+                if (ctx->prof_on)
+                    HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
                 // second stage: the wide register table over the overflow list
                 a.overflow_list = ctx->ovf_list2;
                 a.overflow_count = ctx->ovf_count + 1;
@@ -398,6 +417,31 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             }
         }
     }
+    return MSSPE_OK;
+}
+
+int msspe_profile_enable(msspe_ctx *ctx, int on)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    ctx->prof_on = on != 0;
+    ctx->prof_used = 0;
+    return MSSPE_OK;
+}
+
+int msspe_profile_read(msspe_ctx *ctx, uint64_t *launches, double *total_ms)
+{
+    if (!ctx || !launches || !total_ms) return MSSPE_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i].first, ctx->prof_events[i].second));
+        sum += ms;
+    }
+    *launches = ctx->prof_used;
+    *total_ms = sum;
+    ctx->prof_used = 0;
     return MSSPE_OK;
 }
 

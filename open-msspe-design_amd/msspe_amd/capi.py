@@ -16,7 +16,8 @@ EXPORTS = [
     "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
-    "msspe_last_overflow_pairs", "msspe_oligo_stats_dev", "msspe_oligo_stats",
+    "msspe_last_overflow_pairs", "msspe_profile_enable", "msspe_profile_read",
+    "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
     "msspe_round_fixed_f32", "msspe_g_cut",
 ]
@@ -85,6 +86,8 @@ def load_library() -> C.CDLL:
     L.msspe_cross_dimer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
                                     vp, vp, vp, vp]
     L.msspe_last_overflow_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.msspe_profile_enable.argtypes = [vp, C.c_int]
+    L.msspe_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.msspe_oligo_stats_dev.argtypes = [vp, u64p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
     L.msspe_oligo_stats.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
     L.msspe_kmer_candidates.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), C.c_int,
@@ -211,6 +214,15 @@ class Engine:
             self.ptr, C.c_void_p(d_pool), n, k, C.byref(chem), C.c_float(threshold),
             rows[0], rows[1], cols[0], cols[1], C.c_void_p(d_row_conflicts),
             C.c_void_p(d_bitmap), C.c_void_p(d_dg), C.c_void_p(d_tm)))
+
+    def profile_enable(self, on: bool = True):
+        self._check(self.L.msspe_profile_enable(self.ptr, int(on)))
+
+    def profile_read(self) -> tuple[int, float]:
+        """(launches of the all-pairs kernel, their summed device time in ms) since the last read."""
+        n, ms = C.c_uint64(), C.c_double()
+        self._check(self.L.msspe_profile_read(self.ptr, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
 
     def last_overflow_pairs(self) -> int:
         v = C.c_uint64()
