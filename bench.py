@@ -68,7 +68,7 @@ def cpu_baseline(pool_ascii: np.ndarray, seconds: float, gpu_bitmap_rows: np.nda
     import pyoracle
     tables = pyoracle.Tables()
     n = pool_ascii.shape[0]
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)      # one GPU box grants about 16 host threads
     t0 = time.perf_counter()
     pyoracle.pool_pairs(tables, pool_ascii, rows=(0, 1), threads=1, want_dg=False, want_conflict=False)
     per_row_1t = max(time.perf_counter() - t0, 1e-6)

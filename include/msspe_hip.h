@@ -89,7 +89,8 @@ void msspe_unpack_oligo(uint64_t packed, int k, char *ascii_out /* k+1 bytes */)
  * Outputs (each optional, device pointers):
  *   row_conflicts  uint32[n]            += number of conflicting columns for each row i
  *   bitmap         uint64[(row1-row0) * words], words = ceil((col1-col0)/64): bit (j-col0) of
- *                  row (i-row0) set iff (i,j) conflicts; rows are written whole (no atomics)
+ *                  row (i-row0) set iff (i,j) conflicts; the block is cleared by the call and
+ *                  conflicts (rare) are then set with atomic ORs
  *   dg             double[(row1-row0)*(col1-col0)] raw dG in cal/mol before %g rounding;
  *                  +inf where thal finds no structure (ntthal prints nothing for such a pair;
  *                  this engine defines "no edge")

@@ -54,6 +54,9 @@ struct msspe_ctx {
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
     uint32_t *ovf_count = nullptr;     // [0] first-stage counter, [1] second-stage counter
     uint64_t *d_ovf_total = nullptr;
+    uint64_t *d_sorted = nullptr;      // column primers grouped by composition
+    uint32_t *d_perm = nullptr, *d_bins = nullptr;
+    size_t sort_cap = 0;
     std::string err;
     KmerStage kmer;
     // optional profiling of the dominant kernel (k_pairs_fast) with HIP events on ctx->stream
@@ -159,6 +162,22 @@ int ensure_overflow(msspe_ctx *ctx)
     return MSSPE_OK;
 }
 
+int ensure_sort(msspe_ctx *ctx, size_t ncols)
+{
+    if (!ctx->d_bins)
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bins, sizeof(uint32_t) * (size_t)pool_sort_bins()));
+    if (ctx->sort_cap >= ncols) return MSSPE_OK;
+    if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
+    if (ctx->d_perm) (void)hipFree(ctx->d_perm);
+    ctx->d_sorted = nullptr;
+    ctx->d_perm = nullptr;
+    ctx->sort_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sorted, sizeof(uint64_t) * ncols));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_perm, sizeof(uint32_t) * ncols));
+    ctx->sort_cap = ncols;
+    return MSSPE_OK;
+}
+
 __global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *total += *count;
@@ -246,6 +265,9 @@ void msspe_destroy(msspe_ctx *ctx)
         if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
         if (ctx->ovf_count) (void)hipFree(ctx->ovf_count);
         if (ctx->d_ovf_total) (void)hipFree(ctx->d_ovf_total);
+        if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
+        if (ctx->d_perm) (void)hipFree(ctx->d_perm);
+        if (ctx->d_bins) (void)hipFree(ctx->d_bins);
         if (ctx->d_tb) (void)hipFree(ctx->d_tb);
         for (auto &ev : ctx->prof_events) {
             (void)hipEventDestroy(ev.first);
@@ -329,92 +351,97 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
     const bool fast = !use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok;
+    // the conflict bitmap is produced with atomic ORs: clear the caller's block first
+    if (d_bitmap)
+        HIP_TRY(ctx, hipMemsetAsync(d_bitmap, 0, sizeof(uint64_t) * (size_t)(row1 - row0) * (size_t)words,
+                                    ctx->stream));
+    PairSinks sinks;
+    sinks.row_conflicts = d_row_conflicts;
+    sinks.bitmap = d_bitmap;
+    sinks.dg = d_dg;
+    sinks.tm = d_tm;
+    sinks.row0 = row0;
+    sinks.col0 = col0;
+    sinks.ncols = ncols;
+    sinks.words = words;
+    GenericDimerArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.pt = ce->d_pt;
+    g.c[0] = ce->c[0];
+    g.c[1] = ce->c[1];
+    g.pool = d_pool;
+    g.k = k;
+    g.mode = 1;
+    g.sinks = sinks;
+    g.wsS = ctx->wsS;
+    g.wsH = ctx->wsH;
+    g.ws_lanes = kGenericLanes;
     long rows_per_chunk = kChunkPairs / ncols;
-    if (rows_per_chunk < 1) rows_per_chunk = 1;   // a single row longer than the chunk: see below
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (!fast) {
+        // generic kernel over the whole block, a band of rows per launch (matrix mode derives
+        // (row, col) from sinks.row0 / sinks.col0, so the output base pointers move with the band)
+        for (int r = row0; r < row1; r += (int)rows_per_chunk) {
+            const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
+            GenericDimerArgs gb = g;
+            gb.sinks.row0 = r;
+            gb.n_work = (long)(r_end - r) * (long)ncols;
+            const size_t roff = (size_t)(r - row0);
+            if (gb.sinks.bitmap) gb.sinks.bitmap += roff * (size_t)words;
+            if (gb.sinks.dg) gb.sinks.dg += roff * (size_t)ncols;
+            if (gb.sinks.tm) gb.sinks.tm += roff * (size_t)ncols;
+            HIP_TRY(ctx, launch_dimer_generic(gb, ctx->stream));
+        }
+        return MSSPE_OK;
+    }
+    if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
+    HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
+                                             ctx->d_perm, ctx->stream));
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
         const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
-        for (int c0 = col0; c0 < col1; c0 += (int)kChunkPairs) {
-            const int c_end = (int)std::min<long>(col1, (long)c0 + kChunkPairs);
-            PairSinks sinks;
-            sinks.row_conflicts = d_row_conflicts;
-            // sub-block origin inside the caller's (row0, col0)-based outputs
-            sinks.row0 = row0;
-            sinks.col0 = col0;
-            sinks.ncols = ncols;
-            sinks.words = words;
-            sinks.bitmap = d_bitmap;
-            sinks.dg = d_dg;
-            sinks.tm = d_tm;
-            GenericDimerArgs g;
-            g.pt = ce->d_pt;
-            g.c[0] = ce->c[0];
-            g.c[1] = ce->c[1];
-            g.pool = d_pool;
-            g.k = k;
-            g.mode = 1;
-            g.self_mode = 0;
-            g.self_t = nullptr;
-            g.sinks = sinks;
-            g.wsS = ctx->wsS;
-            g.wsH = ctx->wsH;
-            g.ws_lanes = kGenericLanes;
-            if (fast) {
-                HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
-                PairKernelArgs a;
-                a.ft = ce->d_ft;
-                a.c = ce->c[0];
-                a.pool = d_pool;
-                a.n = n;
-                a.k = k;
-                a.row0 = r;
-                a.row1 = r_end;
-                a.col0 = c0;
-                a.col1 = c_end;
-                a.sinks = sinks;
-                a.overflow_list = ctx->ovf_list;
-                a.overflow_count = ctx->ovf_count;
-                a.overflow_cap = (uint32_t)kChunkPairs;
-                if (ctx->prof_on) {
-                    if (ctx->prof_used == ctx->prof_events.size()) {
-                        hipEvent_t e0, e1;
-                        HIP_TRY(ctx, hipEventCreate(&e0));
-                        HIP_TRY(ctx, hipEventCreate(&e1));
-                        ctx->prof_events.emplace_back(e0, e1);
-                    }
-                    HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
+        for (long q0 = 0; q0 < ncols; q0 += kChunkPairs) {   // sorted-column index range
+            const long q_end = std::min<long>(ncols, q0 + kChunkPairs);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+            PairKernelArgs a;
+            a.ft = ce->d_ft;
+            a.c = ce->c[0];
+            a.pool = d_pool;
+            a.cols_sorted = ctx->d_sorted;
+            a.perm = ctx->d_perm;
+            a.ncols_sorted = ncols;
+            a.n = n;
+            a.k = k;
+            a.row0 = r;
+            a.row1 = r_end;
+            a.col0 = (int)q0;
+            a.col1 = (int)q_end;
+            a.sinks = sinks;
+            a.overflow_list = ctx->ovf_list;
+            a.overflow_count = ctx->ovf_count;
+            a.overflow_cap = (uint32_t)kChunkPairs;
+            if (ctx->prof_on) {
+                if (ctx->prof_used == ctx->prof_events.size()) {
+                    hipEvent_t e0, e1;
+                    HIP_TRY(ctx, hipEventCreate(&e0));
+                    HIP_TRY(ctx, hipEventCreate(&e1));
+                    ctx->prof_events.emplace_back(e0, e1);
                 }
-                HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
-                if (ctx->prof_on)
-                    HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
-                // second stage: the wide register table over the overflow list
-                a.overflow_list = ctx->ovf_list2;
-                a.overflow_count = ctx->ovf_count + 1;
-                HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
-                // third stage: whatever is left (huge tables, both-self-complementary pairs)
-                g.list = ctx->ovf_list2;
-                g.list_count = ctx->ovf_count + 1;
-                g.n_work = (long)(r_end - r) * (long)(c_end - c0);
-                HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
-                hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream,
-                                   ctx->ovf_count, ctx->d_ovf_total);
-            } else {
-                // matrix mode over the sub-block: explicit list-free addressing needs the
-                // sub-block to span whole output rows, so walk it row by row when it does not
-                if (c0 == col0 && c_end == col1) {
-                    g.list = nullptr;
-                    g.list_count = nullptr;
-                    g.sinks.row0 = r;   // matrix mode derives (row, col) from sinks.row0/col0
-                    g.n_work = (long)(r_end - r) * (long)ncols;
-                    // outputs are indexed relative to (row0, col0): shift the base pointers
-                    const size_t roff = (size_t)(r - row0);
-                    if (g.sinks.bitmap) g.sinks.bitmap += roff * (size_t)words;
-                    if (g.sinks.dg) g.sinks.dg += roff * (size_t)ncols;
-                    if (g.sinks.tm) g.sinks.tm += roff * (size_t)ncols;
-                    HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
-                } else {
-                    return fail(ctx, MSSPE_ERR_ARG, "generic path: column range too wide");
-                }
+                HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
+            HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
+            if (ctx->prof_on)
+                HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
+            // second stage: the wide register table over the overflow list
+            a.overflow_list = ctx->ovf_list2;
+            a.overflow_count = ctx->ovf_count + 1;
+            HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
+            // third stage: whatever is left (huge tables, both-self-complementary pairs)
+            g.list = ctx->ovf_list2;
+            g.list_count = ctx->ovf_count + 1;
+            g.n_work = (long)(r_end - r) * (q_end - q0);
+            HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+            hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream,
+                               ctx->ovf_count, ctx->d_ovf_total);
         }
     }
     return MSSPE_OK;

@@ -65,6 +65,9 @@ struct PairKernelArgs {
     const FastTables *ft;      // device
     ThalConsts c;
     const uint64_t *pool;
+    const uint64_t *cols_sorted;   // column primers grouped by composition (pool_sort.hip)
+    const uint32_t *perm;          // cols_sorted[q] == pool[perm[q]]
+    int ncols_sorted;
     int n, k;
     int row0, row1, col0, col1;
     PairSinks sinks;
@@ -78,6 +81,10 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
 hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
                              const uint32_t *in_count, hipStream_t stream);
 int pairs_fast_max_k();
+int pool_sort_bins();
+hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k,
+                                       uint32_t *bins, uint64_t *sorted, uint32_t *perm,
+                                       hipStream_t stream);
 int pairs_fast_main_slots();
 int pairs_fast_wide_slots();
 

@@ -474,6 +474,8 @@ struct FastArgs {
     const FastTables *ft;
     ThalConsts c;
     const uint64_t *pool;
+    const uint64_t *cols_sorted;
+    const uint32_t *perm;
     int k;
     int row0, row1, col0, col1;   // tile range of this launch (matrix mode)
     PairSinks sinks;
@@ -484,7 +486,8 @@ struct FastArgs {
     const uint32_t *in_count;
 };
 
-// Matrix mode: wave = one row x 64 columns.
+// Matrix mode: wave = one row x 64 consecutive entries of the composition-sorted column list.
+// col0/col1 index that sorted list; perm[] maps an entry back to its pool index for the outputs.
 template <int NCH, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
 {
@@ -497,11 +500,12 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
     for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int rg = (int)(tile / ncolg), cg = (int)(tile % ncolg);
         const int row = a.row0 + rg * 4 + wave;
-        const int col = a.col0 + cg * 64 + lane;
+        const int cq = a.col0 + cg * 64 + lane;
         if (row >= a.row1) continue;   // wave-uniform
-        const bool inside = col < a.col1;
+        const bool inside = cq < a.col1;
         const uint64_t pa = a.pool[row];
-        const uint64_t pb = a.pool[inside ? col : a.col0];
+        const uint64_t pb = a.cols_sorted[inside ? cq : a.col0];
+        const int col = (int)a.perm[inside ? cq : a.col0];
         SeqPair q;
         unsigned rowmask;
         int n_cells = setup_pair(pa, pb, a.k, q, rowmask);
@@ -514,15 +518,17 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
         const PairResult r = run_pair<NCH>(T, a.c, q, rowmask, n_cells, nmax);
-        // ---- sinks
+        // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
         const bool live = inside & !spill;
-        const unsigned long long bits = __ballot(live & r.conflict);
+        const bool hit = live & r.conflict;
+        const unsigned long long bits = __ballot(hit);
         const size_t orow = (size_t)(row - a.sinks.row0);
         const size_t ocol = (size_t)(col - a.sinks.col0);
-        if (lane == 0) {
-            if (a.sinks.bitmap) a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)] = bits;
-            if (a.sinks.row_conflicts && bits) atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
-        }
+        if (hit && a.sinks.bitmap)
+            atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
+                     1ull << (ocol & 63));
+        if (lane == 0 && a.sinks.row_conflicts && bits)
+            atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
         if (live) {
             if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
             if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
@@ -587,6 +593,8 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
     f.ft = a.ft;
     f.c = a.c;
     f.pool = a.pool;
+    f.cols_sorted = a.cols_sorted;
+    f.perm = a.perm;
     f.k = a.k;
     f.row0 = a.row0;
     f.row1 = a.row1;
@@ -621,6 +629,8 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
     f.ft = a.ft;
     f.c = a.c;
     f.pool = a.pool;
+    f.cols_sorted = nullptr;
+    f.perm = nullptr;
     f.k = a.k;
     f.row0 = a.row0;
     f.row1 = a.row1;
