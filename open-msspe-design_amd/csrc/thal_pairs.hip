@@ -37,12 +37,25 @@ namespace {
 constexpr int kChunk = 8;
 constexpr int kInterleave = 2;   // predecessor evaluations the scheduler may overlap (register budget)
 
-// The register-resident DP table.  Every access below uses a compile-time slot number (the
-// scans are fully unrolled, the store is a switch), so the arrays dissolve into VGPRs.
-template <int NCH>
+// The DP table of one lane.  Slots [0, NREG*8) live in VGPRs: every access uses a compile-time
+// slot number (switch over the wave-uniform chunk number), so the arrays dissolve into registers.
+// Slots beyond that (rarely reached once the columns are composition-sorted) live in an LDS
+// extension laid out [slot][thread]: the slot number is wave-uniform, so those accesses are
+// conflict-free ds_read/ds_write with a per-lane base.
+template <int NREG, int NEXT>
 struct Slots {
-    double S[NCH * kChunk];
-    int W[NCH * kChunk];
+    static constexpr int kRegSlots = NREG * kChunk;
+    static constexpr int kSlots = (NREG + NEXT) * kChunk;
+    double S[NREG * kChunk];
+    int W[NREG * kChunk];
+    double *xS;   // LDS: &extS[0][threadIdx.x], stride blockDim.x
+    int *xW;
+};
+
+template <int NEXT>
+struct LdsExt {
+    double S[NEXT * kChunk > 0 ? NEXT * kChunk : 1][256];
+    int W[NEXT * kChunk > 0 ? NEXT * kChunk : 1][256];
 };
 
 struct Lds {
@@ -106,7 +119,7 @@ struct Best {
 
 struct SeqPair {
     unsigned s1, s2;     // 2 bits per base; s2 = oligo 2 reversed
-    unsigned m2[4];      // spaced masks of s2: bit 2p set iff base p == x
+    unsigned lenmask;
     int len;
 };
 
@@ -182,18 +195,27 @@ __device__ __forceinline__ void trace_step(const Lds &T, const CellCtx &c, doubl
     h.slot = hit ? p : h.slot;
 }
 
-// Copies chunk `pc` (wave-uniform, dynamic) of the register table into 8 working registers.  The
-// switch keeps every table access compile-time indexed; only the 24 v_mov of one case execute.
-template <int NCH>
-__device__ __forceinline__ void fetch_chunk(const Slots<NCH> &st, int pc, double (&S)[kChunk],
+// Copies chunk `pc` (wave-uniform, dynamic) of the table into 8 working registers.  The switch
+// keeps every register-table access compile-time indexed; only the 24 v_mov of one case execute.
+template <int NREG, int NEXT>
+__device__ __forceinline__ void fetch_chunk(const Slots<NREG, NEXT> &st, int pc, double (&S)[kChunk],
                                             int (&W)[kChunk])
 {
+    if (NEXT > 0 && pc >= NREG) {
+        const int base = (pc - NREG) * kChunk;
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            S[q] = st.xS[(base + q) * 256];
+            W[q] = st.xW[(base + q) * 256];
+        }
+        return;
+    }
 #define MSSPE_FETCH(PC)                                                   \
     case PC:                                                              \
-        if constexpr (PC < NCH) {                                         \
+        if constexpr (PC < NREG) {                                        \
             _Pragma("unroll") for (int q = 0; q < kChunk; ++q) {          \
-                S[q] = st.S[(PC < NCH ? PC : 0) * kChunk + q];            \
-                W[q] = st.W[(PC < NCH ? PC : 0) * kChunk + q];            \
+                S[q] = st.S[(PC < NREG ? PC : 0) * kChunk + q];           \
+                W[q] = st.W[(PC < NREG ? PC : 0) * kChunk + q];           \
             }                                                             \
         }                                                                 \
         break;
@@ -206,8 +228,8 @@ __device__ __forceinline__ void fetch_chunk(const Slots<NCH> &st, int pc, double
 #undef MSSPE_FETCH
 }
 
-template <int NCH>
-__device__ __forceinline__ void scan_fill_all(const Slots<NCH> &st, int upto, const Lds &T,
+template <int NREG, int NEXT>
+__device__ __forceinline__ void scan_fill_all(const Slots<NREG, NEXT> &st, int upto, const Lds &T,
                                               const CellCtx &c, Best &best, double &stS, int &stH,
                                               bool &stHave)
 {
@@ -216,7 +238,7 @@ __device__ __forceinline__ void scan_fill_all(const Slots<NCH> &st, int upto, co
         const int pc = __builtin_amdgcn_readfirstlane(pc_);
         double S[kChunk];
         int W[kChunk];
-        fetch_chunk<NCH>(st, pc, S, W);
+        fetch_chunk<NREG, NEXT>(st, pc, S, W);
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             fill_step(T, c, S[q], W[q], pc * kChunk + q < upto, best, stS, stH, stHave);
@@ -225,8 +247,8 @@ __device__ __forceinline__ void scan_fill_all(const Slots<NCH> &st, int upto, co
     }
 }
 
-template <int NCH>
-__device__ __forceinline__ void scan_trace_all(const Slots<NCH> &st, int upto, const Lds &T,
+template <int NREG, int NEXT>
+__device__ __forceinline__ void scan_trace_all(const Slots<NREG, NEXT> &st, int upto, const Lds &T,
                                                const CellCtx &c, double curS, int curH, int curSlot,
                                                double wcS, int wcH, TraceHit &h)
 {
@@ -235,7 +257,7 @@ __device__ __forceinline__ void scan_trace_all(const Slots<NCH> &st, int upto, c
         const int pc = __builtin_amdgcn_readfirstlane(pc_);
         double S[kChunk];
         int W[kChunk];
-        fetch_chunk<NCH>(st, pc, S, W);
+        fetch_chunk<NREG, NEXT>(st, pc, S, W);
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             trace_step(T, c, S[q], W[q], pc * kChunk + q, curS, curH, curSlot, wcS, wcH, h);
@@ -244,24 +266,10 @@ __device__ __forceinline__ void scan_trace_all(const Slots<NCH> &st, int upto, c
     }
 }
 
-template <int NCH, int P = 0>
-__device__ __forceinline__ void store_elem(Slots<NCH> &st, int slot, double S, int W)
+template <int NREG, int NEXT, int PC = 0>
+__device__ __forceinline__ void store_slot(Slots<NREG, NEXT> &st, int slot, double S, int W)
 {
-    // binary descent over compile-time slot numbers (slot is wave-uniform)
-    if constexpr (P < NCH * kChunk) {
-        if (slot == P) {
-            st.S[P] = S;
-            st.W[P] = W;
-        } else {
-            store_elem<NCH, P + 1>(st, slot, S, W);
-        }
-    }
-}
-
-template <int NCH, int PC = 0>
-__device__ __forceinline__ void store_slot(Slots<NCH> &st, int slot, double S, int W)
-{
-    if constexpr (PC < NCH) {
+    if constexpr (PC < NREG) {
         if (slot < (PC + 1) * kChunk) {
             switch (slot - PC * kChunk) {
             case 0: st.S[PC * kChunk + 0] = S; st.W[PC * kChunk + 0] = W; break;
@@ -274,8 +282,11 @@ __device__ __forceinline__ void store_slot(Slots<NCH> &st, int slot, double S, i
             default: st.S[PC * kChunk + 7] = S; st.W[PC * kChunk + 7] = W; break;
             }
         } else {
-            store_slot<NCH, PC + 1>(st, slot, S, W);
+            store_slot<NREG, NEXT, PC + 1>(st, slot, S, W);
         }
+    } else if constexpr (NEXT > 0) {
+        st.xS[(slot - NREG * kChunk) * 256] = S;
+        st.xW[(slot - NREG * kChunk) * 256] = W;
     }
 }
 
@@ -305,14 +316,16 @@ struct PairResult {
     bool none, conflict;
 };
 
+__device__ __forceinline__ unsigned spaced_mask(unsigned s, int base, unsigned lenmask);
+
 // The whole thal ANY computation for the lane's pair.  n_cells == 0 means "lane idle".
-template <int NCH>
+template <int NREG, int NEXT>
 __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K, const SeqPair &q,
-                                               unsigned rowmask, int n_cells, int nmax)
+                                               unsigned rowmask, int n_cells, int nmax,
+                                               Slots<NREG, NEXT> &st, int ablate = 0)
 {
-    Slots<NCH> st;
 #pragma unroll
-    for (int x = 0; x < NCH * kChunk; ++x) {
+    for (int x = 0; x < NREG * kChunk; ++x) {
         st.S[x] = 0.0;
         st.W[x] = 0;
     }
@@ -324,18 +337,14 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
     c.yTS = c.yMM = c.yAT = c.bB1 = 0;
     unsigned Rrem = rowmask, mrem = 0;
     int im1 = 0, jm1 = 0;
-    // terminal pick (thal.c thal(): strict minimum of the nudged dG, first in row-major order)
-    double pickG = INFINITY, pickS = 0.0, pickRS = 0.0;
-    int pickH = 0, pickRH = 0, pickI = 0, pickJ = 0, pickSlot = 0;
 
     for (int slot_ = 0; slot_ < nmax; ++slot_) {
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
-        const bool active = slot < n_cells;
         // ---- next complementary cell in row-major order
         const bool newrow = mrem == 0;
         const int t = __ffs((int)Rrem) - 1;
         const int a_new = (q.s1 >> (t & 31)) & 3;
-        const unsigned m_new = a_new == 0 ? q.m2[3] : a_new == 1 ? q.m2[2] : a_new == 2 ? q.m2[1] : q.m2[0];
+        const unsigned m_new = spaced_mask(q.s2, 3 - a_new, q.lenmask);
         im1 = newrow ? (t >> 1) : im1;
         Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
         mrem = newrow ? m_new : mrem;
@@ -344,8 +353,6 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         im1 &= 15;
         jm1 &= 15;
         const CellBases b = cell_bases(q, im1, jm1, c);
-        const double leftS = T.S[b.idxL];
-        const int leftH = T.H[b.idxL];
         c.rS = T.S[b.idxR];
         c.rH = T.H[b.idxR];
         // ---- all earlier slots as predecessors
@@ -357,10 +364,10 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         double stS = 0.0;
         int stH = 0;
         bool stHave = false;
-        scan_fill_all<NCH>(st, slot, T, c, best, stS, stH, stHave);
+        if (!(ablate & 1)) scan_fill_all<NREG, NEXT>(st, slot, T, c, best, stS, stH, stHave);
         // ---- thal.c maxTM(): helix extension if it raises Tm
-        double S0 = leftS;
-        int H0 = leftH;
+        double S0 = T.S[b.idxL];
+        int H0 = T.H[b.idxL];
         if (stHave) {
             const double T0 = (double)(H0 + 200 + c.rH) / (((S0 + K.init_S) + c.rS) + K.RC);
             const double S1 = stS + T.S[b.wc];
@@ -377,20 +384,8 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
             S0 = best.S;
             H0 = best.H;
         }
-        // ---- terminal pick
-        const double rSn = c.rS + kTiny, rHn = (double)c.rH + kTiny;
-        const double Gt = (((double)H0 + rHn) + K.init_H) - kT37 * ((S0 + rSn) + K.init_S);
-        const bool pick = active & (Gt < pickG);
-        pickG = pick ? Gt : pickG;
-        pickS = pick ? S0 : pickS;
-        pickH = pick ? H0 : pickH;
-        pickRS = pick ? c.rS : pickRS;
-        pickRH = pick ? c.rH : pickRH;
-        pickI = pick ? im1 : pickI;
-        pickJ = pick ? jm1 : pickJ;
-        pickSlot = pick ? slot : pickSlot;
         // ---- publish the cell (idle lanes write a slot nobody reads)
-        store_slot<NCH>(st, slot, S0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
+        store_slot<NREG, NEXT>(st, slot, S0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
     }
 
     PairResult r;
@@ -399,10 +394,45 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
     r.t = 0.0;
     r.conflict = false;
 
+    // ---- terminal pick (thal.c thal(): strict minimum of the nudged dG over all cells, first in
+    //      row-major order = slot order).  Done as one pass over the finished table so that no
+    //      pick state is carried through the fill loop.
+    double pickG = INFINITY, pickS = 0.0, pickRS = 0.0;
+    int pickH = 0, pickRH = 0, pickI = 0, pickJ = 0, pickSlot = 0;
+    {
+        const int nch = (nmax + kChunk - 1) / kChunk;
+        for (int pc_ = 0; pc_ < nch; ++pc_) {
+            const int pc = __builtin_amdgcn_readfirstlane(pc_);
+            double S[kChunk];
+            int W[kChunk];
+            fetch_chunk<NREG, NEXT>(st, pc, S, W);
+#pragma unroll
+            for (int e = 0; e < kChunk; ++e) {
+                const int slot = pc * kChunk + e;
+                const int ci = (W[e] >> 4) & 15, cj = W[e] & 15, H0 = (W[e] >> 14) * 10;
+                CellCtx dummy;
+                const CellBases b = cell_bases(q, ci, cj, dummy);
+                const double rS = T.S[b.idxR];
+                const int rH = T.H[b.idxR];
+                const double rSn = rS + kTiny, rHn = (double)rH + kTiny;
+                const double Gt = (((double)H0 + rHn) + K.init_H) - kT37 * ((S[e] + rSn) + K.init_S);
+                const bool pick = (slot < n_cells) & (Gt < pickG);
+                pickG = pick ? Gt : pickG;
+                pickS = pick ? S[e] : pickS;
+                pickH = pick ? H0 : pickH;
+                pickRS = pick ? rS : pickRS;
+                pickRH = pick ? rH : pickRH;
+                pickI = pick ? ci : pickI;
+                pickJ = pick ? cj : pickJ;
+                pickSlot = pick ? slot : pickSlot;
+            }
+        }
+    }
+
     // ---- thal.c traceback(): count the base pairs of the optimal structure
     double curS = pickS;
     int curH = pickH, curI = pickI, curJ = pickJ, curSlot = pickSlot, P = 1;
-    bool done = r.none;
+    bool done = r.none | ((ablate & 2) != 0);
     for (int step = 0; step < 2 * 16 + 2; ++step) {
         if (__builtin_amdgcn_readfirstlane((int)__all(done))) break;
         const CellBases b = cell_bases(q, curI, curJ, c);
@@ -414,7 +444,7 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         h.key = 0xffffffffu;
         h.S = 0.0;
         h.H = h.im1 = h.jm1 = h.slot = 0;
-        scan_trace_all<NCH>(st, bound, T, c, curS, curH, curSlot, T.S[b.wc], T.H[b.wc], h);
+        scan_trace_all<NREG, NEXT>(st, bound, T, c, curS, curH, curSlot, T.S[b.wc], T.H[b.wc], h);
         const bool moved = !done & (h.key != 0xffffffffu);
         done = done | !moved;
         curS = moved ? h.S : curS;
@@ -443,20 +473,17 @@ __device__ __forceinline__ int setup_pair(uint64_t pa, uint64_t pb, int k, SeqPa
 {
     const unsigned lenmask = k == 16 ? 0xffffffffu : ((1u << (2 * k)) - 1u);
     q.len = k;
+    q.lenmask = lenmask;
     q.s1 = (unsigned)pa & lenmask;
     q.s2 = reverse2((unsigned)pb & lenmask, k);
-    unsigned m1[4];
     int n_cells = 0;
     rowmask = 0;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        m1[x] = spaced_mask(q.s1, x, lenmask);
-        q.m2[x] = spaced_mask(q.s2, x, lenmask);
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        n_cells += __popc(m1[x]) * __popc(q.m2[3 - x]);
-        rowmask |= q.m2[3 - x] ? m1[x] : 0u;
+        const unsigned m1 = spaced_mask(q.s1, x, lenmask);
+        const unsigned m2 = spaced_mask(q.s2, 3 - x, lenmask);
+        n_cells += __popc(m1) * __popc(m2);
+        rowmask |= m2 ? m1 : 0u;
     }
     return n_cells;
 }
@@ -484,15 +511,21 @@ struct FastArgs {
     uint32_t ovf_cap;
     const uint2 *in_list;         // list mode: explicit pairs
     const uint32_t *in_count;
+    int ablate;                   // timing experiments only: 1 = skip fill scans, 2 = skip traceback
 };
 
 // Matrix mode: wave = one row x 64 consecutive entries of the composition-sorted column list.
 // col0/col1 index that sorted list; perm[] maps an entry back to its pool index for the outputs.
-template <int NCH, int WAVES>
+template <int NREG, int NEXT, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
 {
     __shared__ Lds T;
+    __shared__ LdsExt<NEXT> X;
     load_tables(T, a.ft);
+    Slots<NREG, NEXT> st;
+    st.xS = &X.S[0][threadIdx.x];
+    st.xW = &X.W[0][threadIdx.x];
+    constexpr int NCH = NREG + NEXT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncolg = (a.col1 - a.col0 + 63) >> 6;
     const int nrowg = (a.row1 - a.row0 + 3) >> 2;
@@ -517,7 +550,7 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
         }
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
-        const PairResult r = run_pair<NCH>(T, a.c, q, rowmask, n_cells, nmax);
+        const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st, a.ablate);
         // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
         const bool live = inside & !spill;
         const bool hit = live & r.conflict;
@@ -542,6 +575,9 @@ __global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
 {
     __shared__ Lds T;
     load_tables(T, a.ft);
+    Slots<NCH, 0> st;
+    st.xS = nullptr;
+    st.xW = nullptr;
     const long n_work = (long)min(*a.in_count, a.ovf_cap);
     const long stride = (long)gridDim.x * blockDim.x;
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -562,7 +598,7 @@ __global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
         }
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
-        const PairResult r = run_pair<NCH>(T, a.c, q, rowmask, n_cells, nmax);
+        const PairResult r = run_pair<NCH, 0>(T, a.c, q, rowmask, n_cells, nmax, st);
         if (inside & !spill) {
             const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
             const size_t ocol = (size_t)((int)pr.y - a.sinks.col0);
@@ -578,7 +614,9 @@ __global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
     }
 }
 
-constexpr int kNchMain = 7;    // 56 slots: covers 98.8 % of random 13-mer pairs at 2 waves / SIMD
+constexpr int kNregMain = 5;   // 40 slots in VGPRs ...
+constexpr int kNextMain = 2;   // ... + 16 slots in LDS = 56: 98.8 % of random 13-mer pairs, 2 waves / SIMD
+constexpr int kNchMain = kNregMain + kNextMain;
 constexpr int kNchWide = 16;   // 128 slots: 1 wave / SIMD, for the overflow list
 
 }  // namespace
@@ -606,6 +644,11 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
     f.ovf_cap = a.overflow_cap;
     f.in_list = nullptr;
     f.in_count = nullptr;
+    static const int ablate = [] {
+        const char *e = getenv("MSSPE_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    f.ablate = ablate;
     const long tiles = (long)((a.col1 - a.col0 + 63) / 64) * (long)((a.row1 - a.row0 + 3) / 4);
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L * 8 ? tiles : 256L * 8);
@@ -614,10 +657,12 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
         return e ? atoi(e) : 0;
     }();
     switch (variant) {
-    case 1: hipLaunchKernelGGL((k_pairs_fast<6, 2>), dim3(grid), dim3(256), 0, stream, f); break;
-    case 2: hipLaunchKernelGGL((k_pairs_fast<7, 1>), dim3(grid), dim3(256), 0, stream, f); break;
-    case 3: hipLaunchKernelGGL((k_pairs_fast<5, 2>), dim3(grid), dim3(256), 0, stream, f); break;
-    default: hipLaunchKernelGGL((k_pairs_fast<kNchMain, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    case 1: hipLaunchKernelGGL((k_pairs_fast<6, 1, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    case 2: hipLaunchKernelGGL((k_pairs_fast<7, 0, 1>), dim3(grid), dim3(256), 0, stream, f); break;
+    case 3: hipLaunchKernelGGL((k_pairs_fast<4, 3, 2>), dim3(grid), dim3(256), 0, stream, f); break;
+    default:
+        hipLaunchKernelGGL((k_pairs_fast<kNregMain, kNextMain, 2>), dim3(grid), dim3(256), 0, stream, f);
+        break;
     }
     return hipGetLastError();
 }
@@ -642,6 +687,7 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
     f.ovf_cap = a.overflow_cap;
     f.in_list = in_list;
     f.in_count = in_count;
+    f.ablate = 0;
     hipLaunchKernelGGL(k_pairs_list<kNchWide>, dim3(256 * 2), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
