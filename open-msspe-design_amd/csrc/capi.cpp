@@ -350,7 +350,8 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
 
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
-    const bool fast = !use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok;
+    const bool fast = !use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
+                      chem->max_loop >= 2 * k - 4;   // the tuned kernel has no loop-size cut-off
     // the conflict bitmap is produced with atomic ORs: clear the caller's block first
     if (d_bitmap)
         HIP_TRY(ctx, hipMemsetAsync(d_bitmap, 0, sizeof(uint64_t) * (size_t)(row1 - row0) * (size_t)words,

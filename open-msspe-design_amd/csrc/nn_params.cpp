@@ -447,7 +447,7 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
     (void)t;
     std::memset(&out, 0, sizeof out);
     bool ok = pt.h_is_integral != 0;
-    double min_S = 0.0;     // most negative entropy any single DP step can add
+    double min_S = 0.0;     // most negative entropy any single table term can add
     auto put = [&](int idx, double S, int32_t H) {
         out.S[idx] = S;
         out.H[idx] = H;
@@ -459,43 +459,49 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
     auto addH = [](int32_t a, int32_t b) -> int32_t { return (a >= kHInf || b >= kHInf) ? kHInf : a + b; };
     const double atS[4] = {6.9, 0.0, 0.0, 6.9};
     const int32_t atH[4] = {2200, 0, 0, 2200};
-    for (int z = 0; z < 30; ++z) {
+    // po = a | oa << 2 | ob << 4  ->  PairTables index (a*4 + oa)*4 + ob
+    auto src_of = [](int po) { return ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4); };
+    for (int sz = 2; sz <= FastTables::kMaxSz; ++sz)
         for (int po = 0; po < 64; ++po) {
-            // po = a | oa << 2 | ob << 4  ->  PairTables index (a*4 + oa)*4 + ob
-            const int src = ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4);
-            put(FastTables::kLxI + z * 64 + po, pt.loopS[0][z] + pt.ts_S[src],
-                addH(pt.loopH[0][z], pt.ts_H[src]));
+            const int idx = FastTables::kNB + (sz - 2) * 64 + po;
+            if (sz == 2) put(idx, pt.mm_S[src_of(po)], pt.mm_H[src_of(po)]);
+            else put(idx, pt.loopS[0][sz - 1] + pt.ts_S[src_of(po)], addH(pt.loopH[0][sz - 1], pt.ts_H[src_of(po)]));
         }
-        for (int a = 0; a < 4; ++a)
-            put(FastTables::kLxB + z * 4 + a, pt.loopS[1][z] + atS[a], addH(pt.loopH[1][z], atH[a]));
-    }
     for (int ac = 0; ac < 4; ++ac)
-        for (int ap = 0; ap < 4; ++ap) {
-            double S = pt.loopS[1][0] + pt.wc_S[ap * 4 + ac];
-            int32_t H = addH(pt.loopH[1][0], pt.wc_H[ap * 4 + ac]);
-            if (H >= kHInf || H > 0 || S > 0) {   // thal.c: isPositive(H) || isPositive(S) -> reject
-                S = -1.0;
-                H = kHInf;
+        for (int sz = 0; sz <= FastTables::kMaxSz; ++sz)
+            for (int ap = 0; ap < 4; ++ap) {
+                const int idx = FastTables::kBU + ac * FastTables::kBUStride + sz * 4 + ap;
+                double S = -1.0;
+                int32_t H = kHInf;
+                if (sz == 1) {
+                    S = pt.loopS[1][0] + pt.wc_S[ap * 4 + ac];
+                    H = addH(pt.loopH[1][0], pt.wc_H[ap * 4 + ac]);
+                    if (H >= kHInf || H > 0 || S > 0) {   // thal.c: isPositive(H) || isPositive(S)
+                        S = -1.0;
+                        H = kHInf;
+                    }
+                } else if (sz >= 2) {
+                    S = (pt.loopS[1][sz - 1] + atS[ap]) + atS[ac];
+                    H = addH(addH(pt.loopH[1][sz - 1], atH[ap]), atH[ac]);
+                }
+                put(idx, S, H);
             }
-            put(FastTables::kLxB1 + ac * 4 + ap, S, H);
-        }
-    for (int po = 0; po < 64; ++po) {
-        const int src = ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4);
-        put(FastTables::kMM + po, pt.mm_S[src], pt.mm_H[src]);
-        put(FastTables::kTS + po, pt.ts_S[src], pt.ts_H[src]);
-        put(FastTables::kMMc + po, pt.mm_S[po], pt.mm_H[po]);   // cell side: index is already (x*4+y)*4+z
-        put(FastTables::kTSc + po, pt.ts_S[po], pt.ts_H[po]);
+    for (int ci = 0; ci < 64; ++ci) {
+        put(FastTables::kTSc + ci, pt.ts_S[ci], pt.ts_H[ci]);   // cell side: (x*4+y)*4+z already
+        put(FastTables::kMMc + ci, pt.mm_S[ci], pt.mm_H[ci]);
     }
-    for (int a = 0; a < 4; ++a) put(FastTables::kAT + a, atS[a], atH[a]);
     for (int q = 0; q < 4; ++q) put(FastTables::kZero + q, 0.0, 0);
+    const double ilas = (-300 / 310.15);
+    for (int d = -32; d < 32; ++d) put(FastTables::kZT + 32 + d, ilas * (d < 0 ? -d : d), 0);
     for (int q = 0; q < 100; ++q) {
         put(FastTables::kEndL + q, pt.endL_S[q], pt.endL_H[q]);
         put(FastTables::kEndR + q, pt.endR_S[q], pt.endR_H[q]);
     }
     for (int q = 0; q < 16; ++q) put(FastTables::kWC + q, pt.wc_S[q], pt.wc_H[q]);
-    // clamp reachability: a path has at most max_k pairs, each step adds >= min_S (two table
-    // terms at most per step for interior loops: bounded by 3 * min_S), plus two end terms
+    // clamp reachability: a path has at most max_k pairs and every step adds at most three table
+    // terms, each >= min_S; plus two end terms
     if (3.0 * min_S * (max_k + 2) < -2500.0) ok = false;
+    if (2 * max_k - 4 > FastTables::kMaxSz) ok = false;
     out.usable = ok ? 1 : 0;
     out.max_k = max_k;
     return ok;

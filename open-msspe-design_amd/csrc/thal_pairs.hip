@@ -35,7 +35,7 @@ namespace msspe {
 namespace {
 
 constexpr int kChunk = 8;
-constexpr int kInterleave = 2;   // predecessor evaluations the scheduler may overlap (register budget)
+constexpr int kInterleave = 4;   // predecessor evaluations the scheduler may overlap (register budget)
 
 // The DP table of one lane.  Slots [0, NREG*8) live in VGPRs: every access uses a compile-time
 // slot number (switch over the wave-uniform chunk number), so the arrays dissolve into registers.
@@ -64,11 +64,10 @@ struct Lds {
 };
 
 struct CellCtx {
-    int im1, jm1;            // 0-based cell coordinates (i-1, j-1)
-    int yTS, yMM, yAT, bB1;  // table indices that depend on the cell only
+    int im1p, jm1p;          // cell coordinates minus one: l1 = im1p - ii, l2 = jm1p - jj (0-based)
+    int yTS, yMM, bBase;     // table indices that depend on the cell only
     double rS;               // right end term of the cell
     int rH;
-    int maxloop;
 };
 
 struct Cand {
@@ -80,33 +79,29 @@ struct Cand {
     int iim1, jjm1;
 };
 
-__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
-
 // Candidate value of the loop (or stack) between predecessor slot (Sp, Wp) and cell c.
+// One formula for every kind of loop (fast_tables.hpp); lanes with an impossible geometry read
+// clamped table entries and are masked by `ok`.
 __device__ __forceinline__ Cand make_cand(const Lds &T, const CellCtx &c, double Sp, int Wp)
 {
     Cand r;
     r.jjm1 = Wp & 15;
     r.iim1 = (Wp >> 4) & 15;
     const int po = (Wp >> 8) & 63;
-    const int Hp = (Wp >> 14) * 10;
-    const int l1 = c.im1 - r.iim1 - 1, l2 = c.jm1 - r.jjm1 - 1, sz = l1 + l2;
-    const bool geom = (l1 >= 0) & (l2 >= 0);
-    const bool isBulge = (l1 == 0) | (l2 == 0);
-    const bool sz1 = sz == 1;
-    const bool is1x1 = (l1 == 1) & (l2 == 1);
-    const int a_p = po & 3;
-    int lx = isBulge ? ((sz1 ? c.bB1 : (FastTables::kLxB - 4) + sz * 4) + a_p)
-                     : ((is1x1 ? FastTables::kMM : (FastTables::kLxI - 64) + sz * 64) + po);
-    const int y = isBulge ? (sz1 ? FastTables::kZero : c.yAT) : (is1x1 ? c.yMM : c.yTS);
-    lx = clampi(lx, 0, FastTables::kCount - 1);
-    const int asym = l1 > l2 ? l1 - l2 : l2 - l1;
-    const double Z = isBulge ? 0.0 : kILAS * (double)asym;
-    r.S = ((T.S[lx] + T.S[y]) + Z) + Sp;
-    r.H = T.H[lx] + T.H[y] + Hp;
+    const int l1 = c.im1p - r.iim1, l2 = c.jm1p - r.jjm1, sz = l1 + l2;
+    const int t = min(l1, l2);
+    const bool bulge = t == 0;
+    const int lxN = sz * 64 + po + (FastTables::kNB - 2 * 64);
+    const int lxB = sz * 4 + (po & 3) + c.bBase;
+    const unsigned lx = min((unsigned)(bulge ? lxB : lxN), (unsigned)(FastTables::kCount - 1));
+    const bool m11 = ((l1 << 4) | l2) == 0x11;
+    const int y = bulge ? FastTables::kZero : (m11 ? c.yMM : c.yTS);
+    const int zi = bulge ? FastTables::kZero : (l1 - l2 + (FastTables::kZT + 32));
+    r.S = ((T.S[lx] + T.S[y]) + T.S[zi]) + Sp;
+    r.H = T.H[lx] + T.H[y] + (Wp >> 14) * 10;
     const bool bad = (r.H >= kHInf / 2) | ((r.H > 0) & (r.S > 0.0));
-    r.isStack = geom & (sz == 0);
-    r.ok = geom & (sz > 0) & (sz <= c.maxloop) & !bad;
+    r.isStack = (l1 | l2) == 0;
+    r.ok = (t >= 0) & !bad;
     r.key = (unsigned)(sz * 32 + l1);
     return r;
 }
@@ -141,12 +136,11 @@ __device__ __forceinline__ CellBases cell_bases(const SeqPair &q, int im1, int j
     const int ci = (((3 - b.a) * 4 + (obL & 3)) * 4 + (oaL & 3)) & 63;
     b.wc = FastTables::kWC + (oaL & 3) * 4 + b.a;
     b.po_c = b.a | ((oaR & 3) << 2) | ((obR & 3) << 4);
-    c.im1 = im1;
-    c.jm1 = jm1;
+    c.im1p = im1 - 1;
+    c.jm1p = jm1 - 1;
     c.yTS = FastTables::kTSc + ci;
     c.yMM = FastTables::kMMc + ci;
-    c.yAT = FastTables::kAT + b.a;
-    c.bB1 = FastTables::kLxB1 + b.a * 4;
+    c.bBase = FastTables::kBU + b.a * FastTables::kBUStride;
     return b;
 }
 
@@ -330,11 +324,10 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         st.W[x] = 0;
     }
     CellCtx c;
-    c.maxloop = K.max_loop;
     c.rS = 0.0;
     c.rH = 0;
-    c.im1 = c.jm1 = 0;
-    c.yTS = c.yMM = c.yAT = c.bB1 = 0;
+    c.im1p = c.jm1p = 0;
+    c.yTS = c.yMM = c.bBase = 0;
     unsigned Rrem = rowmask, mrem = 0;
     int im1 = 0, jm1 = 0;
 
