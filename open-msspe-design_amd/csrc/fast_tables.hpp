@@ -26,10 +26,10 @@
 namespace msspe {
 
 struct FastTables {
-    static constexpr int kMaxSz = 30;                          // loop sizes 0..30 are addressable
-    static constexpr int kNB = 0;                              // [sz-2][po], sz = 2..30: 29 * 64
-    static constexpr int kBU = kNB + 29 * 64;                  // [a_c][sz][a_p], sz = 0..30: 4 * 31 * 4
-    static constexpr int kBUStride = 31 * 4;
+    static constexpr int kMaxSz = 28;                          // loop sizes 0..28 (= 2 * 16 - 4) are addressable
+    static constexpr int kNB = 0;                              // [sz-2][po], sz = 2..28: 27 * 64
+    static constexpr int kBU = kNB + (kMaxSz - 1) * 64;        // [a_c][sz][a_p], sz = 0..28: 4 * 29 * 4
+    static constexpr int kBUStride = (kMaxSz + 1) * 4;
     static constexpr int kTSc = kBU + 4 * kBUStride;           // [ci] 64
     static constexpr int kMMc = kTSc + 64;                     // [ci] 64
     static constexpr int kZero = kMMc + 64;                    // 1 (+3 pad)
