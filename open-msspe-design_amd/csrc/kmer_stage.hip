@@ -1,16 +1,450 @@
-// kmer_stage.hip -- placeholder until the stage-A kernels land (next milestone).
+// kmer_stage.hip -- stage A on the device: k-mer candidate generation.
+//
+// Replaces get_segment_manager + make_kmer_segments_windows_mapping + find_candidates_kmers
+// (/root/reference/od-msspe/src/main.rs:196-255, :261-406; exact semantics in SURVEY.md Appendix A):
+//   1. every aligned genome is cut into segments (size 500, stride 250); the k-mers of the head
+//      window (direction 0) or of the tail window, reverse-complemented (direction 1), are
+//      extracted: valid = k consecutive A/C/G/T columns, first occurrence per window only;
+//   2. an inverted index word -> ascending segment list is built (radix sort of 2k-bit keys);
+//   3. the greedy loop picks, up to max_iterations times, the word present in most uncovered
+//      segments (ties: partition_tie_score in f32, then the lexicographically smallest word),
+//      covers its segments and decrements the live counts of every word they hold.
+// The reference rebuilds a string-keyed HashMap over all live segments on every iteration
+// (O(iterations x instances)); here the counts are maintained incrementally, which is exact
+// because a segment is covered at most once.
+//
+// Kernels are HBM-bound integer/byte work: instance arrays are laid out segment-major so that
+// extraction writes and the cover step's reads are coalesced; the sort is hipCUB's radix sort.
 #include "kmer_stage.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace msspe {
 
-int KmerStage::ensure(int, size_t, std::string &) { return MSSPE_OK; }
-void KmerStage::release() {}
+namespace {
 
-int KmerStage::run(const uint8_t *, int, size_t, const msspe_kmer_opt &, int, uint64_t *,
-                   uint32_t *, int, int *, hipStream_t, std::string &err)
+struct Status {
+    int maxf;
+    unsigned n_tied;
+    int winner;
+    int pad;
+};
+
+__device__ __forceinline__ int base2(uint8_t c)
 {
-    err = "stage A kernels are not built into this library yet";
-    return MSSPE_ERR_DEVICE;
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+
+// One thread per (segment, window position).  key = lexicographic-order code of the emitted word
+// (first base in the most significant bits); invalid / duplicate positions get the sentinel.
+__global__ void __launch_bounds__(256) k_extract(const uint8_t *seqs, size_t seq_len, int n_seg,
+                                                 int P, int seg_size, int stride, int W, int k,
+                                                 int direction, int per, int wins_per_block,
+                                                 uint64_t *key_out, uint32_t *val_out)
+{
+    extern __shared__ unsigned char smem[];
+    uint64_t *fkey = (uint64_t *)smem;                           // [wins_per_block][per] forward keys
+    uint8_t *win = smem + sizeof(uint64_t) * wins_per_block * per;   // [wins_per_block][W]
+    const int t = threadIdx.x;
+    const int w = t / per, p = t % per;
+    const long seg0 = (long)blockIdx.x * wins_per_block;
+    // stage the windows
+    for (int e = t; e < wins_per_block * W; e += blockDim.x) {
+        const long seg = seg0 + e / W;
+        uint8_t c = 'N';
+        if (seg < n_seg) {
+            const long rec = seg / P, part = seg % P;
+            const size_t col = (size_t)part * stride + (direction ? seg_size - W : 0) + (e % W);
+            c = seqs[(size_t)rec * seq_len + col];
+        }
+        win[e] = c;
+    }
+    __syncthreads();
+    const long seg = seg0 + w;
+    const bool mine = w < wins_per_block && seg < n_seg;
+    uint64_t fk = ~0ull, word = 0;
+    if (mine) {
+        bool ok = true;
+        uint64_t f = 0, rc = 0;
+        for (int q = 0; q < k; ++q) {
+            const int b = base2(win[w * W + p + q]);
+            ok = ok && b >= 0;
+            f = (f << 2) | (uint64_t)(b & 3);                      // forward word, MSB first
+            rc |= (uint64_t)(3 - (b & 3)) << (2 * q);              // reverse complement, MSB first
+        }
+        if (ok) {
+            fk = f;
+            word = direction ? rc : f;
+        }
+        fkey[w * per + p] = fk;
+    }
+    __syncthreads();
+    if (!mine) return;
+    bool keep = fk != ~0ull;
+    for (int q = 0; keep && q < p; ++q) keep = fkey[w * per + q] != fk;   // first occurrence only
+    const size_t inst = (size_t)seg * per + p;
+    key_out[inst] = keep ? word : (1ull << (2 * k));
+    val_out[inst] = (uint32_t)inst;
+}
+
+__global__ void k_heads(const uint64_t *key, size_t n, uint64_t sentinel, uint32_t *head)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    head[i] = (k != sentinel && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
+}
+
+__global__ void k_index(const uint64_t *key, const uint32_t *val, const uint32_t *head,
+                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per,
+                        int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    const uint32_t inst = val[i];
+    if (k == sentinel) {
+        kid_of_inst[inst] = -1;
+        return;
+    }
+    const uint32_t kid = hscan[i] + head[i] - 1;
+    kid_of_inst[inst] = (int32_t)kid;
+    post[i] = inst / (uint32_t)per;
+    if (head[i]) {
+        post_off[kid] = (uint32_t)i;
+        ukeys[kid] = k;
+    }
+}
+
+// lower bound of the sentinel in the sorted key array (single thread, log n steps)
+__global__ void k_tail(const uint64_t *key, size_t n, uint64_t sentinel, uint32_t *post_off, int M)
+{
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (key[mid] < sentinel) lo = mid + 1;
+        else hi = mid;
+    }
+    post_off[M] = (uint32_t)lo;
+}
+
+__global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) count[i] = (int32_t)(post_off[i + 1] - post_off[i]);
+}
+
+__global__ void k_max_count(const int32_t *count, int M, Status *st)
+{
+    int m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
+        m = max(m, count[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&st->maxf, m);
+}
+
+__global__ void k_collect_tied(const int32_t *count, int M, const Status *st, uint32_t *tied,
+                               unsigned *n_tied)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M && count[i] == st->maxf) tied[atomicAdd(n_tied, 1u)] = (uint32_t)i;
+}
+
+// partition_tie_score (main.rs:261-283): walk the posting list in ascending segment order, skip
+// covered segments, and on the first sight of each partition add 1 / (coverage + 1) in f32.
+// One wave per tied word; `seen` is a per-wave bitmap in LDS.
+__global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const Status *st,
+                                                    const uint32_t *post_off, const uint32_t *post,
+                                                    const uint8_t *ignored, const uint32_t *coverage,
+                                                    int P, float *score)
+{
+    extern __shared__ unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int words = (P + 31) / 32;
+    unsigned *seen = (unsigned *)smem + (size_t)wave * words;
+    const unsigned n = st->n_tied;
+    for (unsigned tix = blockIdx.x * 4 + wave; tix < n; tix += gridDim.x * 4) {
+        for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
+        const uint32_t kid = tied[tix];
+        const uint32_t b = post_off[kid], e = post_off[kid + 1];
+        float acc = 0.0f;
+        for (uint32_t base = b; base < e; base += 64) {
+            const uint32_t i = base + lane;
+            bool fresh = false;
+            int part = 0;
+            if (i < e) {
+                const uint32_t seg = post[i];
+                part = (int)(seg % (uint32_t)P);
+                fresh = !ignored[seg] && !((seen[part >> 5] >> (part & 31)) & 1u);
+            }
+            unsigned long long m = __ballot(fresh);
+            while (m) {   // wave-uniform: candidates in ascending posting order
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int pl = __shfl(part, l);
+                const unsigned wdv = seen[pl >> 5];
+                if (!((wdv >> (pl & 31)) & 1u)) {
+                    if (lane == 0) seen[pl >> 5] = wdv | (1u << (pl & 31));
+                    acc += 1.0f / ((float)coverage[pl] + 1.0f);
+                }
+            }
+        }
+        if (lane == 0) score[tix] = acc;
+    }
+}
+
+// winner = highest score, then smallest word (= smallest id: ids follow the sorted key order)
+__global__ void __launch_bounds__(1024) k_pick_winner(const uint32_t *tied, const float *score,
+                                                      Status *st, const uint64_t *ukeys, int it,
+                                                      uint64_t *out_key, uint32_t *out_freq)
+{
+    __shared__ float bs[1024];
+    __shared__ uint32_t bk[1024];
+    float s = -1.0f;
+    uint32_t kid = 0xffffffffu;
+    for (unsigned i = threadIdx.x; i < st->n_tied; i += blockDim.x) {
+        const float si = score[i];
+        const uint32_t ki = tied[i];
+        if (si > s || (si == s && ki < kid)) {
+            s = si;
+            kid = ki;
+        }
+    }
+    bs[threadIdx.x] = s;
+    bk[threadIdx.x] = kid;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float so = bs[threadIdx.x + off];
+            const uint32_t ko = bk[threadIdx.x + off];
+            if (so > bs[threadIdx.x] || (so == bs[threadIdx.x] && ko < bk[threadIdx.x])) {
+                bs[threadIdx.x] = so;
+                bk[threadIdx.x] = ko;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->winner = (int)bk[0];
+        out_key[it] = ukeys[bk[0]];
+        out_freq[it] = (uint32_t)st->maxf;
+    }
+}
+
+// Cover every segment that holds the winner: bump the partition coverage once per distinct
+// partition (main.rs:371-378, covered segments included) and, for segments covered now, take
+// one off the live count of every word they hold.
+__global__ void __launch_bounds__(256) k_cover(const Status *st, const uint32_t *post_off,
+                                               const uint32_t *post, uint8_t *ignored,
+                                               uint32_t *coverage, uint32_t *stamp, uint32_t it1,
+                                               int P, int per, const int32_t *kid_of_inst,
+                                               int32_t *count)
+{
+    const uint32_t kid = (uint32_t)st->winner;
+    const uint32_t b = post_off[kid], e = post_off[kid + 1];
+    for (uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+        const uint32_t seg = post[i];
+        const uint32_t part = seg % (uint32_t)P;
+        if (atomicExch(&stamp[part], it1) != it1) atomicAdd(&coverage[part], 1u);
+        if (!ignored[seg]) {
+            ignored[seg] = 1;   // a segment appears once per posting list: no race
+            for (int q = 0; q < per; ++q) {
+                const int32_t k2 = kid_of_inst[(size_t)seg * per + q];
+                if (k2 >= 0) atomicSub(&count[k2], 1);
+            }
+        }
+    }
+}
+
+__global__ void k_reset_status(Status *st, unsigned *n_tied)
+{
+    st->maxf = 0;
+    st->n_tied = 0;
+    st->winner = -1;
+    *n_tied = 0;
+}
+
+__global__ void k_publish_tied(Status *st, const unsigned *n_tied) { st->n_tied = *n_tied; }
+
+uint64_t lex_to_packed(uint64_t lex, int k)
+{
+    uint64_t w = 0;
+    for (int p = 0; p < k; ++p) w |= ((lex >> (2 * (k - 1 - p))) & 3ull) << (2 * p);
+    return w;
+}
+
+}  // namespace
+
+int KmerStage::ensure(int slot, size_t bytes, std::string &err)
+{
+    if (cap_[slot] >= bytes) return MSSPE_OK;
+    if (buf_[slot]) (void)hipFree(buf_[slot]);
+    buf_[slot] = nullptr;
+    cap_[slot] = 0;
+    const hipError_t e = hipMalloc(&buf_[slot], bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        err = std::string("hipMalloc (stage A): ") + hipGetErrorString(e);
+        return MSSPE_ERR_DEVICE;
+    }
+    cap_[slot] = bytes;
+    return MSSPE_OK;
+}
+
+void KmerStage::release()
+{
+    for (int s = 0; s < 16; ++s) {
+        if (buf_[s]) (void)hipFree(buf_[s]);
+        buf_[s] = nullptr;
+        cap_[s] = 0;
+    }
+}
+
+#define KM_TRY(expr)                                                        \
+    do {                                                                    \
+        hipError_t e__ = (expr);                                            \
+        if (e__ != hipSuccess) {                                            \
+            err = std::string(#expr) + ": " + hipGetErrorString(e__);       \
+            return MSSPE_ERR_DEVICE;                                        \
+        }                                                                   \
+    } while (0)
+
+int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+                   int direction, uint64_t *words_out, uint32_t *freq_out, int capacity,
+                   int *n_out, hipStream_t stream, std::string &err)
+{
+    *n_out = 0;
+    const int k = opt.kmer_size, W = opt.search_window_size;
+    if (opt.overlap_size < W) {   // main.rs:201-203 panics
+        err = "Overlap windows size must be greater or equal than search windows size";
+        return MSSPE_ERR_ARG;
+    }
+    if (k < 1 || k > 31 || W < k || opt.segment_size < W || opt.overlap_size < 1 ||
+        (direction != 0 && direction != 1) || n_seq < 0 || opt.max_iterations < 0) {
+        err = "stage A: unsupported options (need 1 <= k <= 31, k <= window <= segment, stride >= 1)";
+        return k < 1 || k > 31 ? MSSPE_ERR_K : MSSPE_ERR_ARG;
+    }
+    const long P = seq_len < (size_t)opt.segment_size
+                       ? 0
+                       : (long)((seq_len - (size_t)opt.segment_size) / (size_t)opt.overlap_size) + 1;
+    const long n_seg_l = P * n_seq;
+    if (n_seg_l == 0 || opt.max_iterations == 0) return MSSPE_OK;
+    if (P > 65536 || n_seg_l > 0x7fffffffL / (W - k + 1)) {
+        err = "stage A: alignment too large for 32-bit instance indices";
+        return MSSPE_ERR_ARG;
+    }
+    const int n_seg = (int)n_seg_l;
+    const int per = W - k + 1;
+    const size_t n_inst = (size_t)n_seg * per;
+    const uint64_t sentinel = 1ull << (2 * k);
+    int rc;
+    // buffers: 0/1 keys, 2/3 vals, 4 head, 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
+    // 10 count+tied+score, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp
+    if ((rc = ensure(0, n_inst * 8, err)) || (rc = ensure(1, n_inst * 8, err)) ||
+        (rc = ensure(2, n_inst * 4, err)) || (rc = ensure(3, n_inst * 4, err)) ||
+        (rc = ensure(4, n_inst * 4, err)) || (rc = ensure(5, n_inst * 4, err)) ||
+        (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
+        (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
+        (rc = ensure(10, n_inst * 12, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
+        (rc = ensure(12, (size_t)P * 8, err)) ||
+        (rc = ensure(13, 64 + (size_t)opt.max_iterations * 12, err)))
+        return rc;
+    uint64_t *key_a = (uint64_t *)buf_[0], *key_b = (uint64_t *)buf_[1];
+    uint32_t *val_a = (uint32_t *)buf_[2], *val_b = (uint32_t *)buf_[3];
+    uint32_t *head = (uint32_t *)buf_[4], *hscan = (uint32_t *)buf_[5];
+    int32_t *kid_of_inst = (int32_t *)buf_[6];
+    uint32_t *post = (uint32_t *)buf_[7], *post_off = (uint32_t *)buf_[8];
+    uint64_t *ukeys = (uint64_t *)buf_[9];
+    int32_t *count = (int32_t *)buf_[10];
+    uint32_t *tied = (uint32_t *)buf_[10] + n_inst;
+    float *score = (float *)buf_[10] + 2 * n_inst;
+    uint8_t *ignored = (uint8_t *)buf_[11];
+    uint32_t *coverage = (uint32_t *)buf_[12], *stamp = coverage + P;
+    Status *st = (Status *)buf_[13];
+    unsigned *n_tied = (unsigned *)((char *)buf_[13] + 32);
+    uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 64);
+    uint32_t *out_freq = (uint32_t *)(out_key + opt.max_iterations);
+
+    // 1. extraction
+    const int wins_per_block = std::max(1, 256 / per);
+    const int ext_grid = (n_seg + wins_per_block - 1) / wins_per_block;
+    const size_t ext_lds = sizeof(uint64_t) * wins_per_block * per + (size_t)wins_per_block * W;
+    if (per > 256) {
+        err = "stage A: search window too wide for the extraction kernel";
+        return MSSPE_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_extract, dim3(ext_grid), dim3(256), ext_lds, stream, d_seqs, seq_len, n_seg,
+                       (int)P, opt.segment_size, opt.overlap_size, W, k, direction, per,
+                       wins_per_block, key_a, val_a);
+    KM_TRY(hipGetLastError());
+    // 2. inverted index: stable radix sort on the 2k+1 key bits keeps ascending segment order
+    size_t tmp_bytes = 0, tmp2 = 0;
+    KM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b,
+                                              (int)n_inst, 0, 2 * k + 1, stream));
+    KM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, head, hscan, (int)n_inst, stream));
+    if ((rc = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc;
+    KM_TRY(hipcub::DeviceRadixSort::SortPairs(buf_[14], tmp_bytes, key_a, key_b, val_a, val_b,
+                                              (int)n_inst, 0, 2 * k + 1, stream));
+    const int g_inst = (int)((n_inst + 255) / 256);
+    hipLaunchKernelGGL(k_heads, dim3(g_inst), dim3(256), 0, stream, key_b, n_inst, sentinel, head);
+    KM_TRY(hipcub::DeviceScan::ExclusiveSum(buf_[14], tmp2, head, hscan, (int)n_inst, stream));
+    uint32_t last_head = 0, last_scan = 0;
+    KM_TRY(hipMemcpyAsync(&last_head, head + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+    KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+    KM_TRY(hipStreamSynchronize(stream));
+    const int M = (int)(last_head + last_scan);
+    if (M == 0) return MSSPE_OK;
+    // number of valid instances = first sentinel position: post_off[M]
+    hipLaunchKernelGGL(k_index, dim3(g_inst), dim3(256), 0, stream, key_b, val_b, head, hscan, n_inst,
+                       sentinel, per, kid_of_inst, post, post_off, ukeys);
+    // post_off[M] = number of non-sentinel instances (sentinels sort last)
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, stream, key_b, n_inst, sentinel, post_off, M);
+    hipLaunchKernelGGL(k_init_counts, dim3((M + 255) / 256), dim3(256), 0, stream, post_off, M, count);
+    KM_TRY(hipMemsetAsync(ignored, 0, (size_t)n_seg, stream));
+    KM_TRY(hipMemsetAsync(coverage, 0, (size_t)P * 8, stream));
+    KM_TRY(hipGetLastError());
+
+    // 3. greedy loop
+    const int red_grid = std::min(1024, (M + 255) / 256);
+    const size_t tie_lds = 4 * sizeof(unsigned) * (size_t)((P + 31) / 32);
+    int n_win = 0;
+    for (int it = 0; it < opt.max_iterations; ++it) {
+        hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(1), 0, stream, st, n_tied);
+        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, stream, count, M, st);
+        Status h;
+        KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipStreamSynchronize(stream));
+        if (h.maxf <= 0) break;    // no word left in any live segment (find_most_freq_kmer -> None)
+        if (h.maxf == 1) break;    // main.rs:354-360: a single shared window, stop before the push
+        if (n_win >= capacity) {
+            err = "stage A: more winners than the caller's capacity";
+            return MSSPE_ERR_CAPACITY;
+        }
+        hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, stream, count, M, st,
+                           tied, n_tied);
+        hipLaunchKernelGGL(k_publish_tied, dim3(1), dim3(1), 0, stream, st, n_tied);
+        hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, stream, tied, st, post_off, post,
+                           ignored, coverage, (int)P, score);
+        hipLaunchKernelGGL(k_pick_winner, dim3(1), dim3(1024), 0, stream, tied, score, st, ukeys, n_win,
+                           out_key, out_freq);
+        hipLaunchKernelGGL(k_cover, dim3(64), dim3(256), 0, stream, st, post_off, post, ignored, coverage,
+                           stamp, (uint32_t)(it + 1), (int)P, per, kid_of_inst, count);
+        KM_TRY(hipGetLastError());
+        ++n_win;
+        if (h.maxf < opt.max_mismatch_segments) break;   // main.rs:387-390: stop after the push
+    }
+    if (n_win) {
+        std::vector<uint64_t> hk((size_t)n_win);
+        KM_TRY(hipMemcpyAsync(hk.data(), out_key, sizeof(uint64_t) * n_win, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipMemcpyAsync(freq_out, out_freq, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipStreamSynchronize(stream));
+        for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
+    }
+    *n_out = n_win;
+    return MSSPE_OK;
 }
 
 }  // namespace msspe

@@ -1,0 +1,82 @@
+"""Stage A on the GPU (msspe_kmer_candidates) vs. the oracle's restatement of
+od-msspe/src/main.rs:196-406: winners and frequencies must be identical, in order."""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import window_with_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import msspe_amd
+    e = msspe_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def m():
+    import msspe_amd
+    return msspe_amd
+
+
+def run_both(eng, m, oracle, seqs, seg=500, stride=250, win=50, k=13, iters=1000, mm=1):
+    arr = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).reshape(len(seqs), -1)
+    segs = oracle.Segments(seqs, seg, stride, win, k)
+    for d in (0, 1):
+        opt = m.KmerOpt(seg, stride, win, k, iters, mm)
+        words, freqs = eng.kmer_candidates(arr, opt, d)
+        want = segs.candidates(d, iters, mm)
+        assert list(zip(words, freqs.tolist())) == want, f"direction {d}"
+    return segs
+
+
+def test_reference_unit_vectors_through_the_c_abi(eng, m, oracle, golden_dir):
+    """main.rs:1138-1235 (winner ACT, frequency 2) with the hand-built segments."""
+    g = json.loads((golden_dir / "stage_a_unit.json").read_text())["most_freq"]
+    genome = ""
+    for s in g["segments"]:
+        tail = [oracle.reverse_complement(w) for w in reversed(s["rev"])]
+        genome += window_with_kmers(s["fwd"], 11) + window_with_kmers(tail, 11)
+    arr = np.frombuffer(genome.encode(), dtype=np.uint8).reshape(1, -1)
+    words, freqs = eng.kmer_candidates(arr, m.KmerOpt(22, 22, 11, 3, 1, 1), 0)
+    assert (words, freqs.tolist()) == ([g["winner"]], [g["frequency"]])
+
+
+@pytest.mark.parametrize("n_rows,length,mm", [(10, 3000, 1), (40, 6000, 1), (120, 4000, 3)])
+def test_synthetic_alignments(eng, m, oracle, n_rows, length, mm):
+    genomes = m.synth.aligned_genomes(n_rows, length)
+    seqs = [bytes(r).decode() for r in genomes]
+    segs = run_both(eng, m, oracle, seqs, mm=mm)
+    assert len(segs) == n_rows * ((length - 500) // 250 + 1)
+
+
+def test_small_parameters_and_ties(eng, m, oracle):
+    """Short segments and k = 3 produce many frequency ties: exercises partition_tie_score and
+    the lexicographic tie-break, plus the max_iterations cap."""
+    rng = np.random.default_rng(5)
+    anc = rng.integers(0, 4, 400)
+    seqs = []
+    for _ in range(25):
+        row = anc.copy()
+        mut = rng.random(400) < 0.05
+        row[mut] = rng.integers(0, 4, int(mut.sum()))
+        s = "".join("ACGT"[x] for x in row)
+        seqs.append(s[:120] + "-" * 7 + s[127:300] + "N" * 3 + s[303:])
+    run_both(eng, m, oracle, seqs, seg=40, stride=20, win=12, k=3, iters=1000, mm=1)
+    run_both(eng, m, oracle, seqs, seg=40, stride=20, win=12, k=5, iters=7, mm=1)
+    run_both(eng, m, oracle, seqs, seg=60, stride=30, win=30, k=8, iters=1000, mm=4)
+
+
+def test_edge_inputs(eng, m, oracle):
+    opt = m.KmerOpt(500, 250, 50, 13, 1000, 1)
+    short = np.frombuffer(("ACGT" * 100).encode(), dtype=np.uint8).reshape(1, -1)   # < one segment
+    assert eng.kmer_candidates(short, opt, 0)[0] == []
+    gaps = np.full((4, 1000), ord("-"), dtype=np.uint8)                             # no valid k-mer
+    assert eng.kmer_candidates(gaps, opt, 1)[0] == []
+    with pytest.raises(m.MsspeError):                                               # stride < window
+        eng.kmer_candidates(gaps, m.KmerOpt(500, 40, 50, 13, 10, 1), 0)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""GPU timing of stage A (k-mer candidates) on synthetic alignments (development aid)."""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "open-msspe-design_amd"))
+import numpy as np
+import torch
+import msspe_amd as m
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
+t0 = time.time()
+g = m.synth.aligned_genomes(rows, length)
+print(f"generated {rows} x {length} in {time.time()-t0:.1f} s", flush=True)
+eng = m.Engine(0)
+d = torch.from_numpy(g).cuda()
+opt = m.KmerOpt(500, 250, 50, 13, 1000, max(1, min(10, -(-rows // 50))))
+for direction in (0, 1):
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        words, freqs = eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=rows, seq_len=length)
+        dt = time.time() - t0
+    segs = rows * ((length - 500) // 250 + 1)
+    print(f"dir {direction}: {len(words)} winners, top freq {freqs[:3].tolist()}, {dt*1e3:.1f} ms, "
+          f"{segs/dt/1e6:.2f} M segments/s", flush=True)
