@@ -32,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 import msspe_amd
+from msspe_amd.distributed import gather_pool, reduce_counts, screen_row_block, shard_bounds
 
 K = 13
 THRESHOLD = -9000.0            # od-msspe/src/constants.rs:21
@@ -105,14 +106,13 @@ def main():
     n = args.pool if args.pool else pool_size_for(world)
     n = (n // (64 * world)) * (64 * world)
     shard = n // world
-    r0, r1 = rank * shard, (rank + 1) * shard
+    r0, r1 = shard_bounds(n, world, rank)
     words = n // 64
 
     # synthetic pool (PCG64 seed 20260630); every rank uploads only the candidates it "produced"
     pool_ascii = msspe_amd.synth.random_pool(n, K)
     packed = msspe_amd.pack_oligos(pool_ascii)
     d_shard = torch.from_numpy(packed[r0:r1].view(np.int64).copy()).to(dev)
-    d_pool = torch.empty(n, dtype=torch.int64, device=dev)
     d_conf = torch.zeros(n, dtype=torch.int32, device=dev)
     d_bitmap = torch.zeros((shard, words), dtype=torch.int64, device=dev)
 
@@ -121,15 +121,11 @@ def main():
     chem = msspe_amd.Chem.ntthal()
 
     def step():
-        if world > 1:
-            dist.all_gather_into_tensor(d_pool, d_shard)       # RCCL over xGMI
-        else:
-            d_pool.copy_(d_shard)
+        d_pool = gather_pool(d_shard, n)                       # RCCL all-gather over xGMI (N > 1)
         d_conf.zero_()
-        eng.cross_dimer_dev(d_pool.data_ptr(), n, K, chem, THRESHOLD, (r0, r1), (0, n),
-                            d_conf.data_ptr(), d_bitmap.data_ptr())
-        if world > 1:
-            dist.all_reduce(d_conf)                            # per-primer conflict counts
+        screen_row_block(eng, d_pool, K, chem, THRESHOLD, (r0, r1), d_conf, d_bitmap)
+        reduce_counts(d_conf)                                  # RCCL all-reduce of conflict counts
+        return d_pool
 
     def fence():
         if world > 1:

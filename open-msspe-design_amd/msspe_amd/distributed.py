@@ -1,0 +1,55 @@
+"""Multi-GPU tiling of the cross-dimer pair matrix, one process per GPU.
+
+The O(N^2) pair matrix is cut into row blocks: rank r owns candidates [r0, r1) (the ones it
+produced in stage B) and evaluates them against ALL columns, both orders of every pair being
+covered because every ordered pair (i, j) belongs to exactly one row block.  Two collectives per
+screening round, both a few MB even at 1M candidates:
+    all_gather_into_tensor   packed pool shards  -> full packed pool on every rank
+    all_reduce(sum)          per-primer conflict counts (each rank contributes its rows)
+The conflict bitmap stays sharded by rows.  Works with backend "nccl" (= RCCL over xGMI) on GPUs
+and with "gloo" on CPU tensors (used by the tests to check the tiling logic itself).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous row block of `rank`; blocks differ by at most one row and cover [0, n)."""
+    base, extra = divmod(n, world)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def gather_pool(local_shard: torch.Tensor, n: int) -> torch.Tensor:
+    """All-gather the packed (int64) candidate shards into the full pool of n primers.
+    Shards may differ in length by one: they are padded to the longest for the collective."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local_shard.clone()
+    longest = -(-n // world)
+    padded = torch.zeros(longest, dtype=local_shard.dtype, device=local_shard.device)
+    padded[: local_shard.numel()] = local_shard
+    out = torch.empty(longest * world, dtype=local_shard.dtype, device=local_shard.device)
+    dist.all_gather_into_tensor(out, padded)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(n, world, r)
+        parts.append(out[r * longest: r * longest + (b - a)])
+    return torch.cat(parts)
+
+
+def reduce_counts(local_counts: torch.Tensor) -> torch.Tensor:
+    """Sum the per-primer conflict counts of all ranks in place (each rank filled its rows)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(local_counts, op=dist.ReduceOp.SUM)
+    return local_counts
+
+
+def screen_row_block(engine, d_pool: torch.Tensor, k: int, chem, threshold: float,
+                     rows: tuple[int, int], d_counts: torch.Tensor, d_bitmap: torch.Tensor | None):
+    """Launch the engine on this rank's row block (device tensors; asynchronous)."""
+    n = d_pool.numel()
+    engine.cross_dimer_dev(d_pool.data_ptr(), n, k, chem, threshold, rows, (0, n),
+                           d_counts.data_ptr(), d_bitmap.data_ptr() if d_bitmap is not None else 0)
