@@ -20,3 +20,10 @@ for src in nn_params.cpp capi.cpp kernels_generic.hip thal_pairs.hip pool_sort.h
 done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libmsspe_hip.so" "${objs[@]}" -ldl
 echo "built $here/libmsspe_hip.so"
+# host side above the C ABI (C++17, no HIP): the reference-interface mirror, its CLI and test hooks
+cd "$here/host"
+CXX="${CXX:-g++}"
+"$CXX" -O2 -std=c++17 -fPIC -Wall -shared -o "$here/libod_msspe_host.so" od_msspe.cpp c_hooks.cpp \
+    -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
+"$CXX" -O2 -std=c++17 -Wall -o "$here/od-msspe-hip" main.cpp od_msspe.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
+echo "built $here/libod_msspe_host.so and $here/od-msspe-hip"

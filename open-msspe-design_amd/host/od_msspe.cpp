@@ -1,0 +1,582 @@
+// od_msspe.cpp -- see od_msspe.hpp.  Mirrors /root/reference/od-msspe/src/main.rs, primer.rs,
+// delta_g.rs and config.rs for the hot path and its immediate callers; all arithmetic of the hot
+// path happens in libmsspe_hip.so.
+#include "od_msspe.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <unordered_set>
+
+namespace od_msspe {
+
+// ---------------------------------------------------------------------------------------------
+// CLI (config.rs:11-148)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct OptSpec {
+    const char *flag, *env;
+    enum Kind { Int, OptInt, Float, Bool, Str } kind;
+    size_t offset;
+};
+#define OFF(f) offsetof(Args, f)
+const OptSpec kOpts[] = {
+    {"--kmer-size", "KMER_SIZE", OptSpec::Int, OFF(kmer_size)},
+    {"--window-size", "WINDOW_SIZE", OptSpec::Int, OFF(window_size)},
+    {"--overlap-size", "OVERLAP_SIZE", OptSpec::Int, OFF(overlap_size)},
+    {"--max-mismatch-segments", "MAX_MISMATCH_SEGMENTS", OptSpec::OptInt, OFF(max_mismatch_segments)},
+    {"--max-iterations", "MAX_ITERATIONS", OptSpec::Int, OFF(max_iterations)},
+    {"--search-windows-size", "SEARCH_WINDOWS_SIZE", OptSpec::Int, OFF(search_windows_size)},
+    {"--mv-conc", "MV_CONC", OptSpec::Float, OFF(mv_conc)},
+    {"--dv-conc", "DV_CONC", OptSpec::Float, OFF(dv_conc)},
+    {"--dntp-conc", "DNTP_CONC", OptSpec::Float, OFF(dntp_conc)},
+    {"--dna-conc", "DNA_CONC", OptSpec::Float, OFF(dna_conc)},
+    {"--annealing-temp", "ANNEALING_TEMP", OptSpec::Float, OFF(annealing_temp)},
+    {"--min-tm", "MIN_TM", OptSpec::Float, OFF(min_tm)},
+    {"--max-tm", "MAX_TM", OptSpec::Float, OFF(max_tm)},
+    {"--max-self-dimer-any-tm", "MAX_SELF_DIMER_ANY_TM", OptSpec::Float, OFF(max_self_dimer_any_tm)},
+    {"--max-self-dimer-end-tm", "MAX_SELF_DIMER_END_TM", OptSpec::Float, OFF(max_self_dimer_end_tm)},
+    {"--max-hairpin-tm", "MAX_HAIRPIN_TM", OptSpec::Float, OFF(max_hairpin_tm)},
+    {"--delta-g-threshold", "DELTA_G_THRESHOLD", OptSpec::Float, OFF(delta_g_threshold)},
+    {"--keep-all", "KEEP_ALL", OptSpec::Bool, OFF(keep_all)},
+    {"--check-cross-dimers", "CHECK_CROSS_DIMERS", OptSpec::Bool, OFF(check_cross_dimers)},
+    {"--check-self-dimers", "CHECK_SELF_DIMERS", OptSpec::Bool, OFF(check_self_dimers)},
+    {"--check-hairpin", "CHECK_HAIRPIN", OptSpec::Bool, OFF(check_hairpin)},
+    {"--tm-stddev", "TM_STDDEV", OptSpec::Float, OFF(tm_stddev)},
+    {"--disable-tm-stddev", "DISABLE_TM_STDDEV", OptSpec::Bool, OFF(disable_tm_stddev)},
+    {"--disable-min-max-tm", "DISABLE_MIN_MAX_TM", OptSpec::Bool, OFF(disable_min_max_tm)},
+    {"--do-align", "DO_ALIGN", OptSpec::Bool, OFF(do_align)},
+    {"--ntthal", "NTTHAL", OptSpec::Str, OFF(ntthal)},
+    {"--primer3", "PRIMER3", OptSpec::Str, OFF(primer3)},
+    {"--params-path", "MSSPE_PARAMS_PATH", OptSpec::Str, OFF(params_path)},
+    {"--device", "MSSPE_DEVICE", OptSpec::Int, OFF(device)},
+};
+#undef OFF
+
+void assign(Args &a, const OptSpec &o, const std::string &v)
+{
+    char *base = reinterpret_cast<char *>(&a);
+    char *end = nullptr;
+    switch (o.kind) {
+    case OptSpec::Int:
+    case OptSpec::OptInt: {
+        const long x = std::strtol(v.c_str(), &end, 10);
+        if (v.empty() || *end || x < 0)
+            throw UsageError(std::string("error: invalid value '") + v + "' for '" + o.flag + "'");
+        *reinterpret_cast<int *>(base + o.offset) = (int)x;
+        break;
+    }
+    case OptSpec::Float: {
+        const float x = std::strtof(v.c_str(), &end);
+        if (v.empty() || *end)
+            throw UsageError(std::string("error: invalid value '") + v + "' for '" + o.flag + "'");
+        *reinterpret_cast<float *>(base + o.offset) = x;
+        break;
+    }
+    case OptSpec::Bool:
+        if (v != "true" && v != "false")   // config.rs value_parser = ["true", "false"]
+            throw UsageError(std::string("error: invalid value '") + v + "' for '" + o.flag +
+                             " <...>'\n  [possible values: true, false]");
+        *reinterpret_cast<std::string *>(base + o.offset) = v;
+        break;
+    case OptSpec::Str:
+        *reinterpret_cast<std::string *>(base + o.offset) = v;
+        break;
+    }
+}
+
+}  // namespace
+
+std::string Args::usage()
+{
+    std::string u = "Usage: od-msspe-hip --input <INPUT> --output <OUTPUT> [OPTIONS]\n\nOptions:\n"
+                    "  -i, --input <INPUT>\n  -o, --output <OUTPUT>\n";
+    for (const auto &o : kOpts) u += std::string("      ") + o.flag + " <...>  [env: " + o.env + "=]\n";
+    u += "      --stddev-population   divide the Tm variance by n instead of n-1\n";
+    return u;
+}
+
+Args Args::parse(int argc, const char *const *argv)
+{
+    Args a;
+    for (const auto &o : kOpts)   // environment first, the command line overrides it (clap)
+        if (const char *e = std::getenv(o.env))
+            if (*e) assign(a, o, e);
+    for (int i = 1; i < argc; ++i) {
+        std::string tok = argv[i], val;
+        bool has_val = false;
+        const size_t eq = tok.find('=');
+        if (tok.rfind("--", 0) == 0 && eq != std::string::npos) {
+            val = tok.substr(eq + 1);
+            tok = tok.substr(0, eq);
+            has_val = true;
+        }
+        auto need = [&]() -> std::string {
+            if (has_val) return val;
+            if (i + 1 >= argc)
+                throw UsageError("error: a value is required for '" + tok + " <...>' but none was supplied");
+            return argv[++i];
+        };
+        if (tok == "-h" || tok == "--help") throw UsageError(usage());
+        if (tok == "-i" || tok == "--input") { a.input = need(); continue; }
+        if (tok == "-o" || tok == "--output") { a.output = need(); continue; }
+        if (tok == "--stddev-population") { a.stddev_population = true; continue; }
+        bool found = false;
+        for (const auto &o : kOpts)
+            if (tok == o.flag) {
+                assign(a, o, need());
+                found = true;
+                break;
+            }
+        if (!found) throw UsageError("error: unexpected argument '" + tok + "' found\n\n" + usage());
+    }
+    if (a.input.empty() || a.output.empty())
+        throw UsageError("error: the following required arguments were not provided:\n"
+                         "  --input <INPUT>\n  --output <OUTPUT>\n\n" + usage());
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FASTA (main.rs:108-122; seq_io semantics: id = header up to the first space, lines joined)
+// ---------------------------------------------------------------------------------------------
+std::vector<SequenceRecord> to_records(const std::string &fasta)
+{
+    std::vector<SequenceRecord> out;
+    std::istringstream in(fasta);
+    std::string line;
+    bool have = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            SequenceRecord r;
+            const size_t sp = line.find(' ');
+            r.name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            out.push_back(r);
+            have = true;
+        } else if (have) {
+            for (char c : line) {
+                char u = (char)std::toupper((unsigned char)c);
+                if (u == 'U') u = 'T';
+                out.back().sequence.push_back(u);
+            }
+        }
+    }
+    return out;
+}
+
+std::string reverse_complement(const std::string &s)
+{
+    std::string r(s.rbegin(), s.rend());
+    for (char &c : r) switch (c) {
+        case 'A': c = 'T'; break;
+        case 'T': c = 'A'; break;
+        case 'U': c = 'A'; break;
+        case 'C': c = 'G'; break;
+        case 'G': c = 'C'; break;
+        default: break;
+        }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine handle
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(int device, const std::string &params_path)
+{
+    const int rc = msspe_create(device, params_path.empty() ? nullptr : params_path.c_str(), &ctx_);
+    if (rc) {
+        const std::string msg = ctx_ ? msspe_last_error(ctx_) : "allocation failed";
+        if (ctx_) msspe_destroy(ctx_);
+        ctx_ = nullptr;
+        throw std::runtime_error("msspe_create: " + msg);
+    }
+}
+Engine::~Engine() { if (ctx_) msspe_destroy(ctx_); }
+void Engine::fail(int rc) const
+{
+    throw std::runtime_error(std::string("libmsspe_hip status ") + std::to_string(rc) + ": " +
+                             msspe_last_error(ctx_));
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage A (main.rs:196-235, 331-406)
+// ---------------------------------------------------------------------------------------------
+std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
+                                                 uint8_t direction, const ProgramConfig &cfg,
+                                                 int segment_size, int overlap_size, int window_size)
+{
+    if (overlap_size < window_size)   // main.rs:201-203
+        throw Panic("Overlap windows size must be greater or equal than search windows size");
+    std::vector<KmerFrequency> out;
+    if (records.empty()) return out;
+    // The device path takes one rectangular byte matrix.  Rows shorter than the longest are
+    // padded with '-': partition j starts at the same column in every row (main.rs:173-181), pad
+    // columns invalidate every k-mer that touches them (main.rs:167), so the extra all-pad
+    // partitions of a short row hold no k-mers and can neither be counted nor covered -- the
+    // winners are exactly those of the reference's per-record partitioning.
+    size_t L = 0;
+    for (const auto &r : records) L = std::max(L, r.sequence.size());
+    std::string flat;
+    flat.reserve(L * records.size());
+    for (const auto &r : records) {
+        flat += r.sequence;
+        flat.append(L - r.sequence.size(), '-');
+    }
+    msspe_kmer_opt opt{segment_size, overlap_size, window_size, cfg.primer_config.kmer_size,
+                       cfg.max_iterations, cfg.max_mismatch_segments};
+    const int cap = std::max(1, cfg.max_iterations);
+    std::vector<uint64_t> words((size_t)cap);
+    std::vector<uint32_t> freq((size_t)cap);
+    int n = 0;
+    const int rc = msspe_kmer_candidates(eng.ctx(), reinterpret_cast<const uint8_t *>(flat.data()),
+                                         (int)records.size(), L, &opt, direction, words.data(),
+                                         freq.data(), cap, &n);
+    if (rc) eng.fail(rc);
+    std::vector<char> buf((size_t)opt.kmer_size + 1);
+    for (int i = 0; i < n; ++i) {
+        msspe_unpack_oligo(words[(size_t)i], opt.kmer_size, buf.data());
+        out.push_back({std::string(buf.data()), direction, freq[(size_t)i]});
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage B (primer.rs:143-166; main.rs:408-516)
+// ---------------------------------------------------------------------------------------------
+std::vector<PrimerInfo> check_primers(Engine &eng, const std::vector<std::string> &primers)
+{
+    std::vector<PrimerInfo> out;
+    if (primers.empty()) return out;
+    const int n = (int)primers.size(), k = (int)primers[0].size();
+    std::string flat;
+    for (const auto &p : primers) {
+        if ((int)p.size() != k) throw std::runtime_error("primers of unequal length");
+        flat += p;
+    }
+    std::vector<double> tm((size_t)n), gc((size_t)n), any((size_t)n), end((size_t)n), hp((size_t)n);
+    msspe_chem chem;
+    msspe_chem_primer3_defaults(&chem);   // primer.rs:125-140 sends only size / Tm bounds
+    const int rc = msspe_oligo_stats(eng.ctx(), flat.data(), n, k, &chem, tm.data(), gc.data(),
+                                     any.data(), end.data(), hp.data());
+    if (rc) eng.fail(rc);
+    for (int i = 0; i < n; ++i) {
+        PrimerInfo p;
+        p.id = primers[(size_t)i];
+        p.tm = msspe_round_fixed_f32(tm[(size_t)i], 3);            // PRIMER_LEFT_0_TM=%.3f -> f32
+        p.gc = msspe_round_fixed_f32(gc[(size_t)i], 3);
+        p.self_any_th = msspe_round_fixed_f32(any[(size_t)i], 2);  // ..._TH=%.2f -> f32
+        p.self_end_th = msspe_round_fixed_f32(end[(size_t)i], 2);
+        p.hairpin_th = msspe_round_fixed_f32(hp[(size_t)i], 2);
+        out.push_back(p);
+    }
+    return out;
+}
+
+void get_tm_stat(const std::vector<PrimerInfo> &info, bool population, float &mean, float &std)
+{
+    float sum = 0.0f;
+    for (const auto &p : info) sum += p.tm;   // main.rs:464: sequential f32 sum
+    mean = sum / (float)info.size();
+    float acc = 0.0f;
+    for (const auto &p : info) {
+        const float d = p.tm - mean;
+        acc += d * d;
+    }
+    const float div = population ? (float)info.size() : (float)(info.size() - 1);
+    std = info.size() > (population ? 0u : 1u) ? std::sqrt(acc / div) : 0.0f;
+}
+
+bool tm_in_threshold(float tm, float mean, float std, float diff)
+{
+    return std::fabs(tm - mean) <= (diff * std);
+}
+
+bool is_run(const std::string &kmer)   // main.rs:478-490: only the trailing run counts
+{
+    int runs = 0;
+    char last = ' ';
+    for (char c : kmer) {
+        if (c == last) runs += 1;
+        else runs = 0;
+        last = c;
+    }
+    return runs >= 5;
+}
+
+std::vector<KmerStat> get_kmer_stats(Engine &eng, const std::vector<KmerFrequency> &kmers,
+                                     const ProgramConfig &cfg)
+{
+    std::vector<KmerStat> out;
+    if (kmers.empty()) return out;
+    std::vector<std::string> primers;
+    for (const auto &k : kmers) primers.push_back(k.word);
+    const auto info = check_primers(eng, primers);
+    std::map<std::string, const PrimerInfo *> by_id;
+    for (const auto &p : info) by_id.emplace(p.id, &p);   // first entry wins (or_insert)
+    float mean, std;
+    get_tm_stat(info, cfg.stddev_population, mean, std);
+    for (const auto &k : kmers) {
+        const PrimerInfo *p = by_id.at(k.word);
+        out.push_back({k.word, k.direction, p->gc, mean, std, p->tm,
+                       tm_in_threshold(p->tm, mean, std, cfg.tm_stddev), p->self_any_th,
+                       p->self_end_th, p->hairpin_th, is_run(k.word)});
+    }
+    return out;
+}
+
+std::vector<KmerStat> filter_kmers(const std::vector<KmerStat> &stats, const ProgramConfig &cfg)
+{
+    const PrimerConfig &pc = cfg.primer_config;
+    std::vector<KmerStat> out;
+    for (const auto &s : stats) {
+        const bool pass_self_any = !cfg.check_self_dimers || (s.self_any_th < pc.max_self_dimer_any_tm);
+        const bool pass_self_end = !cfg.check_self_dimers || (s.self_end_th < pc.max_self_dimer_end_tm);
+        const bool pass_hairpin = !cfg.check_hairpin || (s.hairpin_th < pc.max_hairpin_tm);
+        const bool pass_min_max = cfg.disable_min_max_tm || (s.tm > pc.min_tm && s.tm < pc.max_tm);
+        const bool pass_stddev = cfg.disable_tm_stddev || s.tm_ok;
+        if (pass_self_any && pass_self_end && pass_hairpin && pass_min_max && pass_stddev && !s.runs)
+            out.push_back(s);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage C (delta_g.rs:61-153) and the vertex cover (main.rs:754-798)
+// ---------------------------------------------------------------------------------------------
+ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
+                         const NtthalOptions &opts, const ProgramConfig &cfg)
+{
+    ConflictGraph g;
+    // the reference's graph is keyed by the primer string: duplicates collapse into one node
+    std::unordered_set<std::string> seen;
+    for (const auto &p : primers)
+        if (seen.insert(p).second) g.nodes.push_back(p);
+    if (!cfg.check_cross_dimers || g.nodes.empty()) return g;   // delta_g.rs:71-73: no input at all
+    const int n = (int)g.nodes.size(), k = (int)g.nodes[0].size();
+    std::string flat;
+    for (const auto &p : g.nodes) flat += p;
+    const size_t words = ((size_t)n + 63) / 64;
+    std::vector<uint64_t> bitmap((size_t)n * words);
+    auto two = [](float v) {   // ntthal receives "{:.2}" strings of the f32 options (delta_g.rs:98-106)
+        char b[64];
+        std::snprintf(b, sizeof b, "%.2f", (double)v);
+        return std::strtod(b, nullptr);
+    };
+    msspe_chem chem{two(opts.mv), two(opts.dv), two(opts.dntp), two(opts.conc), two(opts.t), 30};
+    const int rc = msspe_cross_dimer(eng.ctx(), flat.data(), n, k, &chem, opts.dg, nullptr,
+                                     bitmap.data(), nullptr, nullptr);
+    if (rc) eng.fail(rc);
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            if (!((bitmap[(size_t)a * words + (size_t)(b >> 6)] >> (b & 63)) & 1ull)) continue;
+            // delta_g.rs:66-69: pairs never sent to ntthal when self-dimer checking is off
+            if (!cfg.check_self_dimers &&
+                (g.nodes[(size_t)a] == g.nodes[(size_t)b] ||
+                 reverse_complement(g.nodes[(size_t)b]) == g.nodes[(size_t)a]))
+                continue;
+            g.edges[g.nodes[(size_t)a]].insert(g.nodes[(size_t)b]);
+        }
+    return g;
+}
+
+std::set<std::string> vertex_cover(const std::vector<std::string> &primers, const ConflictGraph &g)
+{
+    // main.rs:754-771: symmetric adjacency over conflict edges, self loops included
+    std::map<std::string, std::set<std::string>> conflicts;
+    for (const auto &p : primers) {
+        auto it = g.edges.find(p);
+        if (it != g.edges.end())
+            for (const auto &b : it->second) {
+                conflicts[p].insert(b);
+                conflicts[b].insert(p);
+            }
+    }
+    // main.rs:776-798: repeatedly delete the primer with most live conflicts; ties go to the
+    // lexicographically greatest string
+    std::set<std::string> deleted;
+    for (;;) {
+        const std::string *worst = nullptr;
+        size_t worst_count = 0;
+        for (const auto &kv : conflicts) {
+            if (deleted.count(kv.first)) continue;
+            size_t active = 0;
+            for (const auto &nb : kv.second)
+                if (!deleted.count(nb)) ++active;
+            if (active == 0) continue;
+            if (!worst || active > worst_count || (active == worst_count && kv.first > *worst)) {
+                worst = &kv.first;
+                worst_count = active;
+            }
+        }
+        if (!worst) break;
+        deleted.insert(*worst);
+    }
+    return deleted;
+}
+
+// ---------------------------------------------------------------------------------------------
+// report + CSV (main.rs:518-594, 834-858): host-side text
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+std::vector<std::string> window_kmers(const std::string &win, int k)   // main.rs:163-171
+{
+    std::vector<std::string> out;
+    for (size_t p = 0; p + (size_t)k <= win.size(); ++p) {
+        bool ok = true;
+        for (int q = 0; q < k && ok; ++q) {
+            const char c = win[p + (size_t)q];
+            ok = c == 'A' || c == 'T' || c == 'C' || c == 'G' || c == 'U';
+        }
+        if (!ok) continue;
+        std::string w = win.substr(p, (size_t)k);
+        if (std::find(out.begin(), out.end(), w) == out.end()) out.push_back(w);
+    }
+    return out;
+}
+
+std::string fmt(const char *f, double v)
+{
+    char b[64];
+    std::snprintf(b, sizeof b, f, v);
+    return b;
+}
+
+}  // namespace
+
+std::string coverage_report(const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev,
+                            const std::vector<SequenceRecord> &records, int segment_size,
+                            int overlap_size, int window_size, int kmer_size)
+{
+    std::unordered_set<std::string> sel_f, sel_r;
+    for (const auto &p : fwd) sel_f.insert(p.word);
+    for (const auto &p : rev) sel_r.insert(p.word);
+    size_t total = 0, covered = 0;
+    std::map<std::string, std::pair<size_t, size_t>> seq_stats;        // name -> (covered, total)
+    std::map<uint16_t, std::pair<size_t, size_t>> partition_stats;
+    for (const auto &r : records) {
+        const size_t len = r.sequence.size();
+        for (size_t j = 0; (size_t)segment_size <= len && j * (size_t)overlap_size + (size_t)segment_size <= len; ++j) {
+            const std::string part = r.sequence.substr(j * (size_t)overlap_size, (size_t)segment_size);
+            bool hit = false;
+            for (const auto &w : window_kmers(part.substr(0, (size_t)window_size), kmer_size))
+                if (sel_f.count(w)) { hit = true; break; }
+            if (!hit)
+                for (const auto &w : window_kmers(part.substr(part.size() - (size_t)window_size), kmer_size))
+                    if (sel_r.count(reverse_complement(w))) { hit = true; break; }
+            auto &se = seq_stats[r.name];
+            auto &pe = partition_stats[(uint16_t)j];
+            se.second += 1;
+            pe.second += 1;
+            total += 1;
+            if (hit) {
+                se.first += 1;
+                pe.first += 1;
+                covered += 1;
+            }
+        }
+    }
+    float min_cov = INFINITY, max_cov = -INFINITY;
+    size_t well = 0;
+    for (const auto &kv : seq_stats) {
+        const float c = (float)kv.second.first / (float)kv.second.second * 100.0f;
+        min_cov = std::fmin(min_cov, c);
+        max_cov = std::fmax(max_cov, c);
+        if (c >= 80.0f) ++well;
+    }
+    std::string out = "\nCoverage report:\n";
+    out += "  Segments:  " + std::to_string(covered) + "/" + std::to_string(total) + " covered (" +
+           fmt("%.1f", (double)(100.0f * (float)covered / (float)total)) + "%)\n";
+    out += "  Sequences: " + std::to_string(well) + "/" + std::to_string(seq_stats.size()) +
+           " at \xe2\x89\xa5" "80% coverage (min " + fmt("%.1f", (double)min_cov) + "%, max " +
+           fmt("%.1f", (double)max_cov) + "%)\n";
+    std::string unc;
+    for (const auto &kv : partition_stats)
+        if (kv.second.first == 0) unc += (unc.empty() ? "" : ", ") + std::to_string(kv.first);
+    if (unc.empty()) out += "  All partitions have primer coverage\n";
+    else out += "  Uncovered partitions: [" + unc + "]\n";
+    return out;
+}
+
+std::string primers_csv(const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev)
+{
+    std::string out = "direction,name,primers,gc,avg,std,tm\n";
+    for (const auto *list : {&fwd, &rev}) {
+        size_t idx = 0;
+        for (const auto &p : *list) {
+            const char *d = p.direction == SEQ_DIR_FWD ? "F" : "R";
+            out += std::string(d) + ",Primer_" + std::to_string(idx++) + "_" + d + "," + p.word + "," +
+                   fmt("%.2f", (double)(p.gc_percent / 100.0f)) + "," + fmt("%.2f", (double)p.mean) + "," +
+                   fmt("%.2f", (double)p.std) + "," + fmt("%.2f", (double)p.tm) + "\n";
+        }
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// main.rs:596-861
+// ---------------------------------------------------------------------------------------------
+int run(const Args &args, std::string &stdout_text)
+{
+    if (args.do_align == "true")
+        throw std::runtime_error("--do-align true: MAFFT is a host-side pre-step outside this engine; "
+                                 "align the input first and pass --do-align false");
+    std::ifstream f(args.input, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot read " + args.input);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const auto records = to_records(ss.str());
+    if (records.empty()) throw Panic("No sequences found in the input file");
+
+    const int auto_mm = (int)std::min<size_t>(10, std::max<size_t>(1, (records.size() + 49) / 50));
+    ProgramConfig cfg;
+    cfg.max_iterations = args.max_iterations;
+    cfg.max_mismatch_segments = args.max_mismatch_segments >= 0 ? args.max_mismatch_segments : auto_mm;
+    cfg.keep_all = args.keep_all == "true";
+    cfg.check_cross_dimers = args.check_cross_dimers == "true";
+    cfg.check_self_dimers = args.check_self_dimers == "true";
+    cfg.check_hairpin = args.check_hairpin == "true";
+    cfg.tm_stddev = args.tm_stddev;
+    cfg.disable_tm_stddev = args.disable_tm_stddev == "true";
+    cfg.disable_min_max_tm = args.disable_min_max_tm == "true";
+    cfg.primer_config = {args.kmer_size, args.min_tm, args.max_tm, args.max_self_dimer_any_tm,
+                         args.max_self_dimer_end_tm, args.max_hairpin_tm};
+    cfg.stddev_population = args.stddev_population;
+
+    Engine eng(args.device, args.params_path);
+    const auto cand_f = find_candidates_kmers(eng, records, SEQ_DIR_FWD, cfg, args.window_size,
+                                              args.overlap_size, args.search_windows_size);
+    const auto cand_r = find_candidates_kmers(eng, records, SEQ_DIR_REV, cfg, args.window_size,
+                                              args.overlap_size, args.search_windows_size);
+    const auto stats_f = get_kmer_stats(eng, cand_f, cfg);
+    const auto stats_r = get_kmer_stats(eng, cand_r, cfg);
+    const auto prim_f = cfg.keep_all ? stats_f : filter_kmers(stats_f, cfg);
+    const auto prim_r = cfg.keep_all ? stats_r : filter_kmers(stats_r, cfg);
+
+    std::vector<std::string> primers;
+    for (const auto &s : prim_f) primers.push_back(s.word);
+    for (const auto &s : prim_r) primers.push_back(s.word);
+    const NtthalOptions opts{args.mv_conc, args.dv_conc, args.dntp_conc, args.dna_conc,
+                             args.annealing_temp, args.delta_g_threshold};
+    const ConflictGraph graph = run_ntthal(eng, primers, opts, cfg);
+    const auto deleted = vertex_cover(primers, graph);
+    std::vector<KmerStat> good_f, good_r;
+    for (const auto &p : prim_f)
+        if (cfg.keep_all || !deleted.count(p.word)) good_f.push_back(p);
+    for (const auto &p : prim_r)
+        if (cfg.keep_all || !deleted.count(p.word)) good_r.push_back(p);
+
+    stdout_text = coverage_report(good_f, good_r, records, args.window_size, args.overlap_size,
+                                  args.search_windows_size, args.kmer_size);
+    std::ofstream out(args.output, std::ios::binary);
+    if (!out) throw std::runtime_error("cannot write " + args.output);
+    out << primers_csv(good_f, good_r);
+    return 0;
+}
+
+}  // namespace od_msspe

@@ -1,0 +1,150 @@
+"""The C++ host layer (open-msspe-design_amd/host/): CLI parsing with od-msspe's flag and env
+names, FASTA normalisation, vertex cover, CSV and coverage report -- no GPU needed for these."""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "open-msspe-design_amd" / "libod_msspe_host.so"
+
+
+@pytest.fixture(scope="module")
+def host():
+    import msspe_amd
+    msspe_amd.load_library()              # libod_msspe_host.so depends on libmsspe_hip.so
+    return C.CDLL(str(LIB))
+
+
+def call(fn, *args, cap=1 << 20):
+    buf = C.create_string_buffer(cap)
+    rc = fn(*args, buf, cap)
+    return rc, buf.value.decode()
+
+
+def argv(*a):
+    arr = (C.c_char_p * (len(a) + 1))(b"od-msspe-hip", *[x.encode() for x in a])
+    return len(a) + 1, arr
+
+
+def test_cli_flags_follow_config_rs(host, monkeypatch):
+    rc, out = call(host.odm_parse_args, *argv("-i", "in.fa", "-o", "out.csv", "--kmer-size", "15",
+                                              "--check-hairpin=false", "--delta-g-threshold", "-8000"))
+    assert rc == 0
+    kv = dict(l.split("=", 1) for l in out.splitlines())
+    assert kv["kmer_size"] == "15" and kv["check_hairpin"] == "false" and kv["delta_g_threshold"] == "-8000"
+    assert kv["window_size"] == "500" and kv["overlap_size"] == "250" and kv["search_windows_size"] == "50"
+    assert kv["max_iterations"] == "1000" and kv["max_mismatch_segments"] == "-1" and kv["do_align"] == "true"
+    # a bare boolean flag is a usage error: booleans are "true"/"false" strings (config.rs:65-140)
+    rc, out = call(host.odm_parse_args, *argv("-i", "a", "-o", "b", "--check-hairpin"))
+    assert rc == 2 and "a value is required" in out
+    rc, out = call(host.odm_parse_args, *argv("-i", "a", "-o", "b", "--keep-all", "yes"))
+    assert rc == 2 and "possible values: true, false" in out
+    rc, out = call(host.odm_parse_args, *argv("-o", "b"))
+    assert rc == 2 and "--input <INPUT>" in out
+    # every option except -i/-o has an environment fallback; the command line wins
+    monkeypatch.setenv("KMER_SIZE", "11")
+    monkeypatch.setenv("KEEP_ALL", "true")
+    rc, out = call(host.odm_parse_args, *argv("-i", "a", "-o", "b"))
+    kv = dict(l.split("=", 1) for l in out.splitlines())
+    assert kv["kmer_size"] == "11" and kv["keep_all"] == "true"
+    rc, out = call(host.odm_parse_args, *argv("-i", "a", "-o", "b", "--kmer-size", "13"))
+    assert dict(l.split("=", 1) for l in out.splitlines())["kmer_size"] == "13"
+
+
+def test_fasta_normalisation(host):
+    """main.rs:108-122: id up to the first blank, lines joined, upper-cased, U -> T."""
+    rc, out = call(host.odm_to_records, b">seq1 some description\nacgu\nNN-a\r\n>seq2\nUUUU\n")
+    assert out == "seq1\tACGTNN-A\nseq2\tTTTT\n"
+
+
+def test_vertex_cover_rules(host):
+    """main.rs:754-798: most live conflicts first, ties to the lexicographically greatest primer,
+    a self-conflicting primer is always removed."""
+    import ref_pipeline
+    cases = [
+        (["AAA", "CCC", "GGG"], [("AAA", "CCC"), ("GGG", "CCC")]),            # hub CCC goes first
+        (["AAA", "CCC"], [("AAA", "CCC")]),                                    # tie 1-1: CCC (greater)
+        (["AAA", "CCC", "TTT"], [("TTT", "TTT")]),                             # self loop only
+        (["AAA", "CCC", "GGG", "TTT"], [("AAA", "CCC"), ("CCC", "AAA"), ("GGG", "TTT"), ("AAA", "AAA")]),
+        (["ACG", "ACG", "TTT"], [("ACG", "TTT")]),                             # duplicate words collapse
+        (["AAA", "CCC"], []),
+    ]
+    rng = np.random.default_rng(1)
+    words = ["".join("ACGT"[x] for x in rng.integers(0, 4, 5)) for _ in range(14)]
+    cases.append((words, [(words[a], words[b]) for a, b in rng.integers(0, 14, (30, 2))]))
+    for primers, edges in cases:
+        rc, out = call(host.odm_vertex_cover, "\n".join(primers).encode(),
+                       "\n".join(f"{a},{b}" for a, b in edges).encode())
+        assert rc >= 0
+        assert set(out.split()) == ref_pipeline.vertex_cover(primers, set(edges)), (primers, edges)
+
+
+def test_is_run_and_tm_stat(host, oracle):
+    for w in ["ACGTAAAAAA", "AAAAAAACGT", "CCCCCC", "CCCCC", "ACGTTTTTTG"]:
+        assert bool(host.odm_is_run(w.encode())) == oracle.is_run(w)
+    tm = np.array([43.727, 41.5, 47.25, 39.0, 52.125], dtype=np.float32)
+    host.odm_tm_stat.restype = C.c_float
+    sd = C.c_float()
+    mean = host.odm_tm_stat(tm.ctypes.data_as(C.POINTER(C.c_float)), len(tm), 0, C.byref(sd))
+    m2, s2 = oracle.tm_stat(tm, True)
+    assert (np.float32(mean), np.float32(sd.value)) == (np.float32(m2), np.float32(s2))
+
+
+def test_csv_and_coverage_report_text(host, oracle):
+    """main.rs:834-858 (two decimals, gc/100, index restarts per direction) and :518-594."""
+    import ref_pipeline
+    rows = "AGCCCGTGTAAAC,0,53.846,43.25,2.125,43.727\nGGGCCGTGTAAAC,0,61.538,43.25,2.125,47.0\n" \
+           "TTTCCGTGTAAAC,1,38.462,40.0,1.0,39.995"
+    rc, out = call(host.odm_primers_csv, rows.encode())
+    assert out == ("direction,name,primers,gc,avg,std,tm\n"
+                   "F,Primer_0_F,AGCCCGTGTAAAC,0.54,43.25,2.12,43.73\n"
+                   "F,Primer_1_F,GGGCCGTGTAAAC,0.62,43.25,2.12,47.00\n"
+                   "R,Primer_0_R,TTTCCGTGTAAAC,0.38,40.00,1.00,39.99\n")   # f32(39.995) = 39.99499...
+    import msspe_amd
+    g = msspe_amd.synth.aligned_genomes(6, 1400)
+    recs = [(f"s{i}", bytes(r).decode()) for i, r in enumerate(g)]
+    segs = oracle.Segments([s for _, s in recs], 500, 250, 50, 13)
+    fwd = [w for w, _ in segs.candidates(0, 3, 1)]
+    rev = [w for w, _ in segs.candidates(1, 2, 1)]
+    want = ref_pipeline.coverage_report(fwd, rev, recs, 500, 250, 50, 13)
+    rc, out = call(host.odm_coverage_report, "\n".join(f"{n}\t{s}" for n, s in recs).encode(),
+                   "\n".join(fwd).encode(), "\n".join(rev).encode(), 500, 250, 50, 13)
+    assert out == want
+
+
+def test_cli_needs_a_gpu_for_the_pipeline(host, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    fa = tmp_path / "in.fa"
+    fa.write_text(">a\n" + "ACGT" * 200 + "\n")
+    rc, out = call(host.odm_run_cli, *argv("-i", str(fa), "-o", str(tmp_path / "o.csv"), "--do-align", "false"))
+    assert rc == 1 and "no CPU fallback" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,kw", [
+    ([], {}),
+    (["--check-self-dimers", "false", "--max-iterations", "40"], dict(check_self_dimers=False, max_iterations=40)),
+    (["--keep-all", "true", "--max-mismatch-segments", "3"], dict(keep_all=True, max_mismatch_segments=3)),
+    (["--delta-g-threshold", "-4000", "--annealing-temp", "37", "--disable-tm-stddev", "true"],
+     dict(dg=-4000.0, temp=37.0, disable_tm_stddev=True)),
+])
+def test_end_to_end_cli_matches_the_restated_pipeline(host, tmp_path, extra, kw):
+    """Whole run (stage A -> B -> C -> vertex cover -> CSV + report) on a synthetic alignment:
+    the CSV and the report must equal the oracle-based restatement of main.rs byte for byte."""
+    import msspe_amd
+    import ref_pipeline
+    g = msspe_amd.synth.aligned_genomes(24, 3200)
+    fasta = "".join(f">genome{i} synthetic\n{bytes(r).decode()}\n" for i, r in enumerate(g))
+    fa, csv = tmp_path / "in.fa", tmp_path / "out.csv"
+    fa.write_text(fasta)
+    rc, report = call(host.odm_run_cli, *argv("-i", str(fa), "-o", str(csv), "--do-align", "false", *extra))
+    assert rc == 0, report
+    want_csv, want_report, info = ref_pipeline.run(fasta, **kw)
+    assert csv.read_text() == want_csv
+    assert report == want_report
+    assert want_csv.count("\n") > 3
