@@ -111,6 +111,18 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
  * DP did not fit the fast kernel's register-resident table. */
 int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
 
+/* Full thal record for explicit pairs (a_i, b_i), i < n -- what `ntthal` prints per input line
+ * (od-msspe/src/delta_g.rs:206-230): dS (salt-corrected), dH, dG, t and the base pairs of the
+ * traced structure.  mode 1 = ANY, 2 = END1.  Used by the ntthal protocol shim. */
+typedef struct {
+    double dS, dH, dG, t;
+    int32_t no_structure, n_pairs;
+    uint8_t ps1[32];   /* ps1[i-1] = partner position in the REVERSED oligo 2 (1-based), 0 = unpaired */
+    uint8_t ps2[32];
+} msspe_thal_detail;
+int msspe_thal_detail_pairs(msspe_ctx *ctx, const char *a_ascii, const char *b_ascii, int n, int k,
+                            const msspe_chem *chem, int mode, msspe_thal_detail *out);
+
 /* Measurement aid: when enabled, every launch of the dominant kernel (the all-pairs kernel) is
  * bracketed by HIP events on the context's stream; msspe_profile_read() synchronises and returns
  * the number of launches and their summed device time since the last read. */

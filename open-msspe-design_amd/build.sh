@@ -26,4 +26,7 @@ CXX="${CXX:-g++}"
 "$CXX" -O2 -std=c++17 -fPIC -Wall -shared -o "$here/libod_msspe_host.so" od_msspe.cpp c_hooks.cpp \
     -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
 "$CXX" -O2 -std=c++17 -Wall -o "$here/od-msspe-hip" main.cpp od_msspe.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
-echo "built $here/libod_msspe_host.so and $here/od-msspe-hip"
+mkdir -p "$here/bin"
+"$CXX" -O2 -std=c++17 -Wall -o "$here/bin/ntthal-hip" ntthal_shim.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN/..'
+"$CXX" -O2 -std=c++17 -Wall -o "$here/bin/primer3_core-hip" primer3_shim.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN/..'
+echo "built $here/libod_msspe_host.so, $here/od-msspe-hip, bin/ntthal-hip, bin/primer3_core-hip"

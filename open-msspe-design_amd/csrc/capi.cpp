@@ -22,6 +22,7 @@
 #include "kernels.hpp"
 #include "kmer_stage.hpp"
 #include "nn_params.hpp"
+#include "thal_dense.hpp"
 
 using namespace msspe;
 
@@ -542,6 +543,64 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
     if (dg) TRY_OR_CLEAN(hipMemcpy(dg, d_dg, sizeof(double) * nn, hipMemcpyDeviceToHost));
     if (tm) TRY_OR_CLEAN(hipMemcpy(tm, d_tm, sizeof(double) * nn, hipMemcpyDeviceToHost));
     cleanup();
+    return MSSPE_OK;
+}
+
+int msspe_thal_detail_pairs(msspe_ctx *ctx, const char *a_ascii, const char *b_ascii, int n, int k,
+                            const msspe_chem *chem, int mode, msspe_thal_detail *out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!a_ascii || !b_ascii || !chem || !out || n < 0 || (mode != 1 && mode != 2))
+        return fail(ctx, MSSPE_ERR_ARG, "null argument or unsupported mode (1 = ANY, 2 = END1)");
+    if (k < 2 || k > 32) return fail(ctx, MSSPE_ERR_K, "oligo length must be 2..32");
+    if (n == 0) return MSSPE_OK;
+    static_assert(sizeof(msspe_thal_detail) == sizeof(ThalDetail), "detail layouts differ");
+    std::vector<uint64_t> packed((size_t)2 * n);
+    int rc = msspe_pack_oligos(a_ascii, n, k, packed.data());
+    if (!rc) rc = msspe_pack_oligos(b_ascii, n, k, packed.data() + n);
+    if (rc) return fail(ctx, rc, "oligos hold characters other than ACGT");
+    std::vector<uint2> list((size_t)n);
+    for (int i = 0; i < n; ++i) list[(size_t)i] = make_uint2((unsigned)i, (unsigned)(n + i));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ChemEntry *ce = nullptr;
+    if ((rc = chem_entry(ctx, *chem, -9000.0f, &ce))) return rc;
+    if ((rc = ensure_workspace(ctx, (size_t)k * (size_t)k))) return rc;
+    uint64_t *d_pool = nullptr;
+    uint2 *d_list = nullptr;
+    ThalDetail *d_det = nullptr;
+    auto cleanup = [&]() {
+        if (d_pool) (void)hipFree(d_pool);
+        if (d_list) (void)hipFree(d_list);
+        if (d_det) (void)hipFree(d_det);
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_pool, sizeof(uint64_t) * 2 * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_list, sizeof(uint2) * (size_t)n)) != hipSuccess ||
+        (e = hipMalloc((void **)&d_det, sizeof(ThalDetail) * (size_t)n)) != hipSuccess ||
+        (e = hipMemcpy(d_pool, packed.data(), sizeof(uint64_t) * 2 * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_list, list.data(), sizeof(uint2) * (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return hip_fail(ctx, e, "thal detail buffers");
+    }
+    GenericDimerArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.pt = ce->d_pt;
+    g.c[0] = ce->c[0];
+    g.c[1] = ce->c[1];
+    g.pool = d_pool;
+    g.k = k;
+    g.mode = mode;
+    g.list = d_list;
+    g.n_work = n;
+    g.detail = d_det;
+    g.wsS = ctx->wsS;
+    g.wsH = ctx->wsH;
+    g.ws_lanes = kGenericLanes;
+    e = launch_dimer_generic(g, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_det, sizeof(ThalDetail) * (size_t)n, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(ctx, e, "thal detail");
     return MSSPE_OK;
 }
 

@@ -35,6 +35,7 @@ struct GenericDimerArgs {
     long n_work;
     int self_mode;
     double *self_t;
+    void *detail;              // optional ThalDetail[n_work] (list mode; thal_dense.hpp)
     PairSinks sinks;
     double *wsS, *wsH;         // workspace planes, [cell][lane], lanes = ws_lanes
     size_t ws_lanes;

@@ -52,8 +52,19 @@ __global__ void __launch_bounds__(256) k_dimer_generic(GenericDimerArgs a)
         ctx.s2 = Seq{reverse_packed(pb, a.k), a.k};
         ctx.m = Planes{a.wsS + lane, a.wsH + lane, a.ws_lanes, a.k};
         ThalOut o;
-        ctx.run(a.mode, o);
-        if (a.self_mode) {
+        ThalDetail *det = a.detail ? (ThalDetail *)a.detail + w : nullptr;
+        if (det) {
+            for (int q = 0; q < 32; ++q) det->ps1[q] = det->ps2[q] = 0;
+        }
+        ctx.run(a.mode, o, det);
+        if (det) {
+            det->dS = o.dS;
+            det->dH = o.dH;
+            det->dG = o.dG;
+            det->t = o.t;
+            det->no_structure = o.none;
+            det->n_pairs = o.n_pairs;
+        } else if (a.self_mode) {
             a.self_t[w] = (o.none || o.t < 0.0) ? 0.0 : o.t;   // libprimer3 align_thermod()
         } else {
             sink_pair(a.sinks, ctx.c, row, col, o);

@@ -34,6 +34,15 @@ struct ThalOut {
     int none;   // 1: no structure
 };
 
+// Full per-pair record for callers that print what ntthal prints (the protocol shim): the
+// thermodynamic values plus the base pairs of the traced structure.  Layout == msspe_thal_detail.
+struct ThalDetail {
+    double dS, dH, dG, t;
+    int32_t no_structure, n_pairs;
+    uint8_t ps1[32];   // ps1[i-1] = partner j in the REVERSED oligo 2 (1-based), 0 = unpaired
+    uint8_t ps2[32];
+};
+
 // 2-bit packed oligo with N sentinels outside [1, len]
 struct Seq {
     uint64_t bits;
@@ -226,10 +235,15 @@ struct DimerCtx {
             }
     }
 
-    // thal.c traceback(): returns the number of base pairs on the optimal path from (i,j)
-    __device__ int traceback(int i, int j) const
+    // thal.c traceback(): returns the number of base pairs on the optimal path from (i,j);
+    // records them in d->ps1 / d->ps2 when a detail record is requested
+    __device__ int traceback(int i, int j, ThalDetail *det = nullptr) const
     {
         int pairs = 1;
+        if (det) {
+            det->ps1[i - 1] = (uint8_t)j;
+            det->ps2[j - 1] = (uint8_t)i;
+        }
         int guard = 4 * (s1.len + s2.len) + 8;
         while (guard-- > 0) {
             double lS, lH;
@@ -245,6 +259,10 @@ struct DimerCtx {
                     --j;
                     ++pairs;
                     done = true;
+                    if (det) {
+                        det->ps1[i - 1] = (uint8_t)j;
+                        det->ps2[j - 1] = (uint8_t)i;
+                    }
                 }
             }
             for (int d = 3; !done && d <= c.max_loop + 2; ++d) {
@@ -263,6 +281,10 @@ struct DimerCtx {
                         j = jj;
                         ++pairs;
                         done = true;
+                        if (det) {
+                            det->ps1[i - 1] = (uint8_t)j;
+                            det->ps2[j - 1] = (uint8_t)i;
+                        }
                     }
                 }
             }
@@ -271,7 +293,7 @@ struct DimerCtx {
         return pairs;
     }
 
-    __device__ void run(int mode, ThalOut &o)
+    __device__ void run(int mode, ThalOut &o, ThalDetail *d = nullptr)
     {
         fill();
         int bi = 0, bj = 0;
@@ -302,7 +324,7 @@ struct DimerCtx {
         right(bi, bj, rS, rH);
         const double dH = m.h(bi, bj) + rH + c.init_H;
         const double dS = m.s(bi, bj) + rS + c.init_S;
-        const int P = traceback(bi, bj);
+        const int P = traceback(bi, bj, d);
         const int N = P - 1;
         o.none = 0;
         o.n_pairs = P;
