@@ -35,7 +35,7 @@ namespace msspe {
 namespace {
 
 constexpr int kChunk = 8;
-constexpr int kInterleave = 4;   // predecessor evaluations the scheduler may overlap (register budget)
+constexpr int kInterleave = 2;   // predecessor evaluations the scheduler may overlap (register budget)
 
 // The DP table of one lane.  Slots [0, NREG*8) live in VGPRs: every access uses a compile-time
 // slot number (switch over the wave-uniform chunk number), so the arrays dissolve into registers.
@@ -79,30 +79,67 @@ struct Cand {
     int iim1, jjm1;
 };
 
-// Candidate value of the loop (or stack) between predecessor slot (Sp, Wp) and cell c.
+// Candidate value of the loop (or stack) between predecessor slot (Sp, Wp) and cell c, in three
+// phases so that a group of predecessors can issue all its LDS gathers before any is consumed
+// (one s_waitcnt per group instead of three per predecessor):
+//   geometry  -> table indices          (integer VALU)
+//   gather    -> five LDS reads         (ds_read)
+//   finish    -> sums, rejection tests  (f64 VALU)
 // One formula for every kind of loop (fast_tables.hpp); lanes with an impossible geometry read
 // clamped table entries and are masked by `ok`.
-__device__ __forceinline__ Cand make_cand(const Lds &T, const CellCtx &c, double Sp, int Wp)
+struct CandGeom {
+    int l1, l2, t, sz;
+    unsigned lx;
+    int y, zi;
+    int iim1, jjm1;
+};
+struct CandLoad {
+    double sLX, sY, sZ;
+    int hLX, hY;
+};
+
+__device__ __forceinline__ CandGeom cand_geometry(const CellCtx &c, int Wp)
+{
+    CandGeom g;
+    g.jjm1 = Wp & 15;
+    g.iim1 = (Wp >> 4) & 15;
+    const int po = (Wp >> 8) & 63;
+    g.l1 = c.im1p - g.iim1;
+    g.l2 = c.jm1p - g.jjm1;
+    g.sz = g.l1 + g.l2;
+    g.t = min(g.l1, g.l2);
+    const bool bulge = g.t == 0;
+    const int lxN = g.sz * 64 + po + (FastTables::kNB - 2 * 64);
+    const int lxB = g.sz * 4 + (po & 3) + c.bBase;
+    g.lx = min((unsigned)(bulge ? lxB : lxN), (unsigned)(FastTables::kCount - 1));
+    const bool m11 = ((g.l1 << 4) | g.l2) == 0x11;
+    g.y = bulge ? FastTables::kZero : (m11 ? c.yMM : c.yTS);
+    g.zi = bulge ? FastTables::kZero : (g.l1 - g.l2 + (FastTables::kZT + 32));
+    return g;
+}
+
+__device__ __forceinline__ CandLoad cand_gather(const Lds &T, const CandGeom &g)
+{
+    CandLoad v;
+    v.sLX = T.S[g.lx];
+    v.sY = T.S[g.y];
+    v.sZ = T.S[g.zi];
+    v.hLX = T.H[g.lx];
+    v.hY = T.H[g.y];
+    return v;
+}
+
+__device__ __forceinline__ Cand cand_finish(const CandGeom &g, const CandLoad &v, double Sp, int Wp)
 {
     Cand r;
-    r.jjm1 = Wp & 15;
-    r.iim1 = (Wp >> 4) & 15;
-    const int po = (Wp >> 8) & 63;
-    const int l1 = c.im1p - r.iim1, l2 = c.jm1p - r.jjm1, sz = l1 + l2;
-    const int t = min(l1, l2);
-    const bool bulge = t == 0;
-    const int lxN = sz * 64 + po + (FastTables::kNB - 2 * 64);
-    const int lxB = sz * 4 + (po & 3) + c.bBase;
-    const unsigned lx = min((unsigned)(bulge ? lxB : lxN), (unsigned)(FastTables::kCount - 1));
-    const bool m11 = ((l1 << 4) | l2) == 0x11;
-    const int y = bulge ? FastTables::kZero : (m11 ? c.yMM : c.yTS);
-    const int zi = bulge ? FastTables::kZero : (l1 - l2 + (FastTables::kZT + 32));
-    r.S = ((T.S[lx] + T.S[y]) + T.S[zi]) + Sp;
-    r.H = T.H[lx] + T.H[y] + (Wp >> 14) * 10;
+    r.iim1 = g.iim1;
+    r.jjm1 = g.jjm1;
+    r.S = ((v.sLX + v.sY) + v.sZ) + Sp;
+    r.H = v.hLX + v.hY + (Wp >> 14) * 10;
     const bool bad = (r.H >= kHInf / 2) | ((r.H > 0) & (r.S > 0.0));
-    r.isStack = (l1 | l2) == 0;
-    r.ok = (t >= 0) & !bad;
-    r.key = (unsigned)(sz * 32 + l1);
+    r.isStack = (g.l1 | g.l2) == 0;
+    r.ok = (g.t >= 0) & !bad;
+    r.key = (unsigned)(g.sz * 32 + g.l1);
     return r;
 }
 
@@ -147,10 +184,9 @@ __device__ __forceinline__ CellBases cell_bases(const SeqPair &q, int im1, int j
 // ---- register-table access: slot numbers are compile-time constants ---------------------------
 
 // Fill: one predecessor slot against cell c.  `on` masks slots that are not computed yet.
-__device__ __forceinline__ void fill_step(const Lds &T, const CellCtx &c, double Sp, int Wp, bool on,
+__device__ __forceinline__ void fill_step(const Cand &k, const CellCtx &c, double Sp, int Wp, bool on,
                                           Best &best, double &stS, int &stH, bool &stHave)
 {
-    const Cand k = make_cand(T, c, Sp, Wp);
     const double G1 = (double)(k.H + c.rH) - kT37 * (k.S + c.rS);
     const bool better = on & k.ok & ((G1 < best.G) | ((G1 == best.G) & (k.key < best.key)));
     best.G = better ? G1 : best.G;
@@ -170,11 +206,10 @@ struct TraceHit {
 };
 
 // Traceback: does predecessor slot p reproduce the current cell's value?
-__device__ __forceinline__ void trace_step(const Lds &T, const CellCtx &c, double Sp, int Wp, int p,
+__device__ __forceinline__ void trace_step(const Cand &k, double Sp, int Wp, int p,
                                            double curS, int curH, int curSlot, double wcS, int wcH,
                                            TraceHit &h)
 {
-    const Cand k = make_cand(T, c, Sp, Wp);
     const int Hp = (Wp >> 14) * 10;
     const double candS = k.isStack ? wcS + Sp : k.S;
     const int candH = k.isStack ? wcH + Hp : k.H;
@@ -234,9 +269,20 @@ __device__ __forceinline__ void scan_fill_all(const Slots<NREG, NEXT> &st, int u
         int W[kChunk];
         fetch_chunk<NREG, NEXT>(st, pc, S, W);
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            fill_step(T, c, S[q], W[q], pc * kChunk + q < upto, best, stS, stH, stHave);
-            if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
+        for (int q0 = 0; q0 < kChunk; q0 += kInterleave) {
+            if (pc * kChunk + q0 >= upto) break;   // wave-uniform: nothing computed yet past here
+            CandGeom g[kInterleave];
+            CandLoad v[kInterleave];
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) g[e] = cand_geometry(c, W[q0 + e]);
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) v[e] = cand_gather(T, g[e]);
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) {
+                const Cand k = cand_finish(g[e], v[e], S[q0 + e], W[q0 + e]);
+                fill_step(k, c, S[q0 + e], W[q0 + e], pc * kChunk + q0 + e < upto, best, stS, stH, stHave);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -253,9 +299,20 @@ __device__ __forceinline__ void scan_trace_all(const Slots<NREG, NEXT> &st, int 
         int W[kChunk];
         fetch_chunk<NREG, NEXT>(st, pc, S, W);
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
-            trace_step(T, c, S[q], W[q], pc * kChunk + q, curS, curH, curSlot, wcS, wcH, h);
-            if ((q & (kInterleave - 1)) == kInterleave - 1) __builtin_amdgcn_sched_barrier(0);
+        for (int q0 = 0; q0 < kChunk; q0 += kInterleave) {
+            if (pc * kChunk + q0 >= upto) break;   // wave-uniform
+            CandGeom g[kInterleave];
+            CandLoad v[kInterleave];
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) g[e] = cand_geometry(c, W[q0 + e]);
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) v[e] = cand_gather(T, g[e]);
+#pragma unroll
+            for (int e = 0; e < kInterleave; ++e) {
+                const Cand k = cand_finish(g[e], v[e], S[q0 + e], W[q0 + e]);
+                trace_step(k, S[q0 + e], W[q0 + e], pc * kChunk + q0 + e, curS, curH, curSlot, wcS, wcH, h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
