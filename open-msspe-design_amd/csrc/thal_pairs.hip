@@ -268,21 +268,32 @@ __device__ __forceinline__ void scan_fill_all(const Slots<NREG, NEXT> &st, int u
         double S[kChunk];
         int W[kChunk];
         fetch_chunk<NREG, NEXT>(st, pc, S, W);
+        // software pipeline over groups of kInterleave predecessors: the gathers of group n+1 are
+        // in flight while group n is finished
+        constexpr int kGroups = kChunk / kInterleave;
+        CandGeom g[2][kInterleave];
+        CandLoad v[2][kInterleave];
 #pragma unroll
-        for (int q0 = 0; q0 < kChunk; q0 += kInterleave) {
-            if (pc * kChunk + q0 >= upto) break;   // wave-uniform: nothing computed yet past here
-            CandGeom g[kInterleave];
-            CandLoad v[kInterleave];
+        for (int e = 0; e < kInterleave; ++e) g[0][e] = cand_geometry(c, W[e]);
 #pragma unroll
-            for (int e = 0; e < kInterleave; ++e) g[e] = cand_geometry(c, W[q0 + e]);
+        for (int e = 0; e < kInterleave; ++e) v[0][e] = cand_gather(T, g[0][e]);
 #pragma unroll
-            for (int e = 0; e < kInterleave; ++e) v[e] = cand_gather(T, g[e]);
+        for (int grp = 0; grp < kGroups; ++grp) {
+            const int q0 = grp * kInterleave;
+            const int cur = grp & 1, nxt = cur ^ 1;
+            const bool more = grp + 1 < kGroups && pc * kChunk + q0 + kInterleave < upto;   // wave-uniform
+            if (more) {
+#pragma unroll
+                for (int e = 0; e < kInterleave; ++e) g[nxt][e] = cand_geometry(c, W[q0 + kInterleave + e]);
+#pragma unroll
+                for (int e = 0; e < kInterleave; ++e) v[nxt][e] = cand_gather(T, g[nxt][e]);
+            }
 #pragma unroll
             for (int e = 0; e < kInterleave; ++e) {
-                const Cand k = cand_finish(g[e], v[e], S[q0 + e], W[q0 + e]);
+                const Cand k = cand_finish(g[cur][e], v[cur][e], S[q0 + e], W[q0 + e]);
                 fill_step(k, c, S[q0 + e], W[q0 + e], pc * kChunk + q0 + e < upto, best, stS, stH, stHave);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!more) break;
         }
     }
 }
