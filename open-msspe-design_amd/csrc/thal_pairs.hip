@@ -35,6 +35,7 @@ namespace msspe {
 namespace {
 
 constexpr int kChunk = 8;
+constexpr int kEmptySlot = 0xff;   // packed word of a slot that holds no cell yet: i-1 = j-1 = 15
 constexpr int kInterleave = 2;   // predecessor evaluations the scheduler may overlap (register budget)
 
 // The DP table of one lane.  Slots [0, NREG*8) live in VGPRs: every access uses a compile-time
@@ -184,16 +185,16 @@ __device__ __forceinline__ CellBases cell_bases(const SeqPair &q, int im1, int j
 // ---- register-table access: slot numbers are compile-time constants ---------------------------
 
 // Fill: one predecessor slot against cell c.  `on` masks slots that are not computed yet.
-__device__ __forceinline__ void fill_step(const Cand &k, const CellCtx &c, double Sp, int Wp, bool on,
+__device__ __forceinline__ void fill_step(const Cand &k, const CellCtx &c, double Sp, int Wp,
                                           Best &best, double &stS, int &stH, bool &stHave)
 {
     const double G1 = (double)(k.H + c.rH) - kT37 * (k.S + c.rS);
-    const bool better = on & k.ok & ((G1 < best.G) | ((G1 == best.G) & (k.key < best.key)));
+    const bool better = k.ok & ((G1 < best.G) | ((G1 == best.G) & (k.key < best.key)));
     best.G = better ? G1 : best.G;
     best.S = better ? k.S : best.S;
     best.H = better ? k.H : best.H;
     best.key = better ? k.key : best.key;
-    const bool st = on & k.isStack;
+    const bool st = k.isStack;
     stS = st ? Sp : stS;
     stH = st ? (Wp >> 14) * 10 : stH;
     stHave = stHave | st;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void scan_fill_all(const Slots<NREG, NEXT> &st, int u
 #pragma unroll
             for (int e = 0; e < kInterleave; ++e) {
                 const Cand k = cand_finish(g[cur][e], v[cur][e], S[q0 + e], W[q0 + e]);
-                fill_step(k, c, S[q0 + e], W[q0 + e], pc * kChunk + q0 + e < upto, best, stS, stH, stHave);
+                fill_step(k, c, S[q0 + e], W[q0 + e], best, stS, stH, stHave);
             }
             if (!more) break;
         }
@@ -386,10 +387,16 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
                                                unsigned rowmask, int n_cells, int nmax,
                                                Slots<NREG, NEXT> &st, int ablate = 0)
 {
+    // Every slot starts as "not computed yet": coordinates (16,16) lie beyond any cell, so such a
+    // slot fails the geometry test of every cell and needs no separate mask in the scans.
 #pragma unroll
     for (int x = 0; x < NREG * kChunk; ++x) {
         st.S[x] = 0.0;
-        st.W[x] = 0;
+        st.W[x] = kEmptySlot;
+    }
+    if constexpr (NEXT > 0) {
+#pragma unroll
+        for (int x = 0; x < NEXT * kChunk; ++x) st.xW[x * 256] = kEmptySlot;
     }
     CellCtx c;
     c.rS = 0.0;
