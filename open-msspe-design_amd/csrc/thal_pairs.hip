@@ -587,12 +587,18 @@ struct FastArgs {
 template <int NREG, int NEXT, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
 {
-    __shared__ Lds T;
-    __shared__ LdsExt<NEXT> X;
+    // one LDS object with the tables FIRST: their byte offsets stay below 64 KB, so every table
+    // gather folds its array base into the ds_read immediate offset
+    struct Shared {
+        Lds T;
+        LdsExt<NEXT> X;
+    };
+    __shared__ Shared sh;
+    Lds &T = sh.T;
     load_tables(T, a.ft);
     Slots<NREG, NEXT> st;
-    st.xS = &X.S[0][threadIdx.x];
-    st.xW = &X.W[0][threadIdx.x];
+    st.xS = &sh.X.S[0][threadIdx.x];
+    st.xW = &sh.X.W[0][threadIdx.x];
     constexpr int NCH = NREG + NEXT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncolg = (a.col1 - a.col0 + 63) >> 6;
