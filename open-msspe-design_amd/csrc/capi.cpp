@@ -37,7 +37,8 @@ struct ChemEntry {
     bool fast_ok = false;
 };
 
-constexpr long kChunkPairs = 1L << 24;       // pairs per fast launch == overflow-list capacity
+constexpr long kChunkPairs = 1L << 24;       // pairs per launch of the all-pairs kernel
+constexpr long kListCap = 1L << 27;          // overflow-list entries: 8 launches can never overrun it
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace
@@ -154,8 +155,8 @@ int ensure_workspace(msspe_ctx *ctx, size_t cells_per_lane)
 int ensure_overflow(msspe_ctx *ctx)
 {
     if (ctx->ovf_list) return MSSPE_OK;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)kChunkPairs));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)kChunkPairs));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)kListCap));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)kListCap));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
@@ -399,11 +400,50 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
     HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
                                              ctx->d_perm, ctx->stream));
+    // Overflow pairs are collected over several launches and finished together: the list kernels
+    // have a fixed latency floor, and kListCap entries cannot be overrun by kListCap / kChunkPairs
+    // launches even if every pair overflowed.
+    auto flush = [&]() -> int {
+        PairKernelArgs a;
+        a.ft = ce->d_ft;
+        a.c = ce->c[0];
+        a.pool = d_pool;
+        a.cols_sorted = nullptr;
+        a.perm = nullptr;
+        a.ncols_sorted = 0;
+        a.n = n;
+        a.k = k;
+        a.row0 = row0;
+        a.row1 = row1;
+        a.col0 = 0;
+        a.col1 = ncols;
+        a.sinks = sinks;
+        // second stage: the wide table over the overflow list
+        a.overflow_list = ctx->ovf_list2;
+        a.overflow_count = ctx->ovf_count + 1;
+        a.overflow_cap = (uint32_t)kListCap;
+        HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
+        // third stage: whatever is left (huge tables, both-self-complementary pairs)
+        g.list = ctx->ovf_list2;
+        g.list_count = ctx->ovf_count + 1;
+        g.n_work = kListCap;
+        HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+        hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
+                           ctx->d_ovf_total);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+        return MSSPE_OK;
+    };
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    long pending = 0;   // worst-case entries the list may hold
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
         const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
         for (long q0 = 0; q0 < ncols; q0 += kChunkPairs) {   // sorted-column index range
             const long q_end = std::min<long>(ncols, q0 + kChunkPairs);
-            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+            const long launch_pairs = (long)(r_end - r) * (q_end - q0);
+            if (pending + launch_pairs > kListCap) {
+                if ((rc = flush())) return rc;
+                pending = 0;
+            }
             PairKernelArgs a;
             a.ft = ce->d_ft;
             a.c = ce->c[0];
@@ -420,7 +460,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             a.sinks = sinks;
             a.overflow_list = ctx->ovf_list;
             a.overflow_count = ctx->ovf_count;
-            a.overflow_cap = (uint32_t)kChunkPairs;
+            a.overflow_cap = (uint32_t)kListCap;
             if (ctx->prof_on) {
                 if (ctx->prof_used == ctx->prof_events.size()) {
                     hipEvent_t e0, e1;
@@ -433,19 +473,10 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
             if (ctx->prof_on)
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
-            // second stage: the wide register table over the overflow list
-            a.overflow_list = ctx->ovf_list2;
-            a.overflow_count = ctx->ovf_count + 1;
-            HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
-            // third stage: whatever is left (huge tables, both-self-complementary pairs)
-            g.list = ctx->ovf_list2;
-            g.list_count = ctx->ovf_count + 1;
-            g.n_work = (long)(r_end - r) * (q_end - q0);
-            HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
-            hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream,
-                               ctx->ovf_count, ctx->d_ovf_total);
+            pending += launch_pairs;
         }
     }
+    if (pending && (rc = flush())) return rc;
     return MSSPE_OK;
 }
 

@@ -49,14 +49,15 @@ struct Slots {
     static constexpr int kSlots = (NREG + NEXT) * kChunk;
     double S[NREG * kChunk];
     int W[NREG * kChunk];
-    double *xS;   // LDS: &extS[0][threadIdx.x], stride blockDim.x
+    double *xS;   // LDS: &extS[0][threadIdx.x]
     int *xW;
+    int xstride;  // threads per block (elements between consecutive extension slots)
 };
 
-template <int NEXT>
+template <int NEXT, int THREADS>
 struct LdsExt {
-    double S[NEXT * kChunk > 0 ? NEXT * kChunk : 1][256];
-    int W[NEXT * kChunk > 0 ? NEXT * kChunk : 1][256];
+    double S[NEXT * kChunk > 0 ? NEXT * kChunk : 1][THREADS];
+    int W[NEXT * kChunk > 0 ? NEXT * kChunk : 1][THREADS];
 };
 
 struct Lds {
@@ -235,8 +236,8 @@ __device__ __forceinline__ void fetch_chunk(const Slots<NREG, NEXT> &st, int pc,
         const int base = (pc - NREG) * kChunk;
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
-            S[q] = st.xS[(base + q) * 256];
-            W[q] = st.xW[(base + q) * 256];
+            S[q] = st.xS[(base + q) * st.xstride];
+            W[q] = st.xW[(base + q) * st.xstride];
         }
         return;
     }
@@ -348,8 +349,8 @@ __device__ __forceinline__ void store_slot(Slots<NREG, NEXT> &st, int slot, doub
             store_slot<NREG, NEXT, PC + 1>(st, slot, S, W);
         }
     } else if constexpr (NEXT > 0) {
-        st.xS[(slot - NREG * kChunk) * 256] = S;
-        st.xW[(slot - NREG * kChunk) * 256] = W;
+        st.xS[(slot - NREG * kChunk) * st.xstride] = S;
+        st.xW[(slot - NREG * kChunk) * st.xstride] = W;
     }
 }
 
@@ -396,7 +397,7 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
     }
     if constexpr (NEXT > 0) {
 #pragma unroll
-        for (int x = 0; x < NEXT * kChunk; ++x) st.xW[x * 256] = kEmptySlot;
+        for (int x = 0; x < NEXT * kChunk; ++x) st.xW[x * st.xstride] = kEmptySlot;
     }
     CellCtx c;
     c.rS = 0.0;
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
     // gather folds its array base into the ds_read immediate offset
     struct Shared {
         Lds T;
-        LdsExt<NEXT> X;
+        LdsExt<NEXT, 256> X;
     };
     __shared__ Shared sh;
     Lds &T = sh.T;
@@ -599,6 +600,7 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
     Slots<NREG, NEXT> st;
     st.xS = &sh.X.S[0][threadIdx.x];
     st.xW = &sh.X.W[0][threadIdx.x];
+    st.xstride = 256;
     constexpr int NCH = NREG + NEXT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncolg = (a.col1 - a.col0 + 63) >> 6;
@@ -643,15 +645,23 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
     }
 }
 
-// List mode: lane = one explicit pair (the overflow list of the matrix kernel).
-template <int NCH>
-__global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
+// List mode: lane = one explicit pair (the overflow list of the matrix kernel).  128-thread
+// blocks: 40 register slots + NEXT * 8 LDS slots per lane, two blocks per CU.
+template <int NREG, int NEXT>
+__global__ void __launch_bounds__(128, 1) k_pairs_list(FastArgs a)
 {
-    __shared__ Lds T;
+    struct Shared {
+        Lds T;
+        LdsExt<NEXT, 128> X;
+    };
+    __shared__ Shared sh;
+    Lds &T = sh.T;
     load_tables(T, a.ft);
-    Slots<NCH, 0> st;
-    st.xS = nullptr;
-    st.xW = nullptr;
+    Slots<NREG, NEXT> st;
+    st.xS = &sh.X.S[0][threadIdx.x];
+    st.xW = &sh.X.W[0][threadIdx.x];
+    st.xstride = 128;
+    constexpr int NCH = NREG + NEXT;
     const long n_work = (long)min(*a.in_count, a.ovf_cap);
     const long stride = (long)gridDim.x * blockDim.x;
     const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,7 +682,7 @@ __global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
         }
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
-        const PairResult r = run_pair<NCH, 0>(T, a.c, q, rowmask, n_cells, nmax, st);
+        const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st);
         if (inside & !spill) {
             const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
             const size_t ocol = (size_t)((int)pr.y - a.sinks.col0);
@@ -691,7 +701,9 @@ __global__ void __launch_bounds__(256, 1) k_pairs_list(FastArgs a)
 constexpr int kNregMain = 5;   // 40 slots in VGPRs ...
 constexpr int kNextMain = 2;   // ... + 16 slots in LDS = 56: 98.8 % of random 13-mer pairs, 2 waves / SIMD
 constexpr int kNchMain = kNregMain + kNextMain;
-constexpr int kNchWide = 16;   // 128 slots: 1 wave / SIMD, for the overflow list
+constexpr int kNregWide = 5;   // overflow list: 40 slots in VGPRs ...
+constexpr int kNextWide = 4;   // ... + 32 in LDS = 72 (all but 0.012 % of random 13-mer pairs)
+constexpr int kNchWide = kNregWide + kNextWide;
 
 }  // namespace
 
@@ -762,7 +774,7 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
     f.in_list = in_list;
     f.in_count = in_count;
     f.ablate = 0;
-    hipLaunchKernelGGL(k_pairs_list<kNchWide>, dim3(256 * 2), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL((k_pairs_list<kNregWide, kNextWide>), dim3(256 * 4), dim3(128), 0, stream, f);
     return hipGetLastError();
 }
 
