@@ -449,7 +449,10 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
     bool ok = pt.h_is_integral != 0;
     double min_S = 0.0;     // most negative entropy any single table term can add
     auto put = [&](int idx, double S, int32_t H) {
-        out.S[idx] = S;
+        // an unavailable entry carries a huge positive entropy next to its huge enthalpy, so that
+        // the kernel's single rejection test "H > 0 and S > 0" (thal.c's both-positive rule)
+        // also catches it, whatever finite terms are added on top
+        out.S[idx] = H >= kHInf ? 1e300 : S;
         out.H[idx] = H;
         if (H < kHInf) {
             if (H % 10 != 0) ok = false;

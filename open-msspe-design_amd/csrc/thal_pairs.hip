@@ -138,7 +138,7 @@ __device__ __forceinline__ Cand cand_finish(const CandGeom &g, const CandLoad &v
     r.jjm1 = g.jjm1;
     r.S = ((v.sLX + v.sY) + v.sZ) + Sp;
     r.H = v.hLX + v.hY + (Wp >> 14) * 10;
-    const bool bad = (r.H >= kHInf / 2) | ((r.H > 0) & (r.S > 0.0));
+    const bool bad = (r.H > 0) & (r.S > 0.0);   // also true for unavailable table entries
     r.isStack = (g.l1 | g.l2) == 0;
     r.ok = (g.t >= 0) & !bad;
     r.key = (unsigned)(g.sz * 32 + g.l1);
