@@ -10,18 +10,25 @@
 //     a 256-thread block covers 4 rows x 64 columns and loops over tiles (persistent grid).
 //   * the DP is SPARSE: only complementary cells (about 42 of 169 for random 13-mers) exist; they
 //     are enumerated per lane in row-major order and numbered 0..n-1 ("slots").
-//   * the per-pair DP table lives in VGPRs, not LDS: slot s keeps S (f64) and a packed word
-//     {H/10, predecessor context, i, j}.  All lanes walk slots in lock-step, so the slot number is
-//     wave-uniform and the register file is indexed through M0 (s_set_gpr_idx / v_mov), which
-//     costs no LDS bandwidth, no bank conflicts and no occupancy for a [slot][lane] LDS image.
-//   * LDS holds only the 2.4k-entry thermodynamic tables (fast_tables.hpp), gathered per lane.
+//   * the per-pair DP table lives in VGPRs, not in an LDS image: slot s keeps S (f64) and a
+//     packed word {H/10, predecessor context, i, j}.  All lanes walk slots in lock-step, so the
+//     slot number is wave-uniform: a switch over the (uniform) chunk number copies 8 slots into
+//     working registers with compile-time register numbers (24 v_mov per 8 predecessors).  Slots
+//     40..55 overflow into a small LDS extension laid out [slot][thread] (conflict-free because
+//     the slot is uniform).  No spills, 256 VGPRs, two 256-thread blocks per CU.
+//   * every predecessor is evaluated in three phases (integer geometry -> five LDS gathers ->
+//     f64 finish) and the scan is software-pipelined over groups of two predecessors, so LDS
+//     latency overlaps the previous group's arithmetic.
+//   * LDS holds the 2.6k-entry thermodynamic tables (fast_tables.hpp), gathered per lane.
 //   * enthalpies are exact integers (checked on the host) and are summed in int32; entropies are
 //     summed in f64 in Primer3's operation order (file built with -ffp-contract=off), so dS, dH,
 //     dG and t are bit-identical to the CPU oracle and decisions are identical by construction.
 //   * min-dG over predecessors is order independent except for exact ties, which are resolved by
 //     Primer3's visiting order (key = loop size, then row distance).
-//   * the conflict bit of the 64 lanes leaves the wave as one ballot word (bitmap) and one
-//     popcount atomic (per-row conflict count): 0.125 B + 1/16 B of HBM traffic per check.
+//   * the columns of a launch are sorted by base composition (pool_sort.hip), which gives the 64
+//     lanes of a wave equal DP sizes; conflicts (0.5 % of random pairs) leave the wave as one
+//     atomic OR per conflicting pair at its ORIGINAL column and one popcount atomic per wave for
+//     the per-row conflict count.
 // Pairs whose DP has more complementary cells than the register table holds go to an overflow
 // list and are finished by the wide instantiation of this kernel (list mode) or the generic kernel.
 #include <cstdlib>
