@@ -31,8 +31,6 @@
 //     the per-row conflict count.
 // Pairs whose DP has more complementary cells than the register table holds go to an overflow
 // list and are finished by the wide instantiation of this kernel (list mode) or the generic kernel.
-#include <cstdlib>
-
 #include "fast_tables.hpp"
 #include "kernels.hpp"
 #include "thal_dense.hpp"
@@ -393,7 +391,7 @@ __device__ __forceinline__ unsigned spaced_mask(unsigned s, int base, unsigned l
 template <int NREG, int NEXT>
 __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K, const SeqPair &q,
                                                unsigned rowmask, int n_cells, int nmax,
-                                               Slots<NREG, NEXT> &st, int ablate = 0)
+                                               Slots<NREG, NEXT> &st)
 {
     // Every slot starts as "not computed yet": coordinates (16,16) lie beyond any cell, so such a
     // slot fails the geometry test of every cell and needs no separate mask in the scans.
@@ -440,7 +438,7 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         double stS = 0.0;
         int stH = 0;
         bool stHave = false;
-        if (!(ablate & 1)) scan_fill_all<NREG, NEXT>(st, slot, T, c, best, stS, stH, stHave);
+        scan_fill_all<NREG, NEXT>(st, slot, T, c, best, stS, stH, stHave);
         // ---- thal.c maxTM(): helix extension if it raises Tm
         double S0 = T.S[b.idxL];
         int H0 = T.H[b.idxL];
@@ -508,7 +506,7 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
     // ---- thal.c traceback(): count the base pairs of the optimal structure
     double curS = pickS;
     int curH = pickH, curI = pickI, curJ = pickJ, curSlot = pickSlot, P = 1;
-    bool done = r.none | ((ablate & 2) != 0);
+    bool done = r.none;
     for (int step = 0; step < 2 * 16 + 2; ++step) {
         if (__builtin_amdgcn_readfirstlane((int)__all(done))) break;
         const CellBases b = cell_bases(q, curI, curJ, c);
@@ -587,7 +585,6 @@ struct FastArgs {
     uint32_t ovf_cap;
     const uint2 *in_list;         // list mode: explicit pairs
     const uint32_t *in_count;
-    int ablate;                   // timing experiments only: 1 = skip fill scans, 2 = skip traceback
 };
 
 // Matrix mode: wave = one row x 64 consecutive entries of the composition-sorted column list.
@@ -633,7 +630,7 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
         }
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
-        const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st, a.ablate);
+        const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st);
         // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
         const bool live = inside & !spill;
         const bool hit = live & r.conflict;
@@ -737,26 +734,10 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
     f.ovf_cap = a.overflow_cap;
     f.in_list = nullptr;
     f.in_count = nullptr;
-    static const int ablate = [] {
-        const char *e = getenv("MSSPE_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
-    f.ablate = ablate;
     const long tiles = (long)((a.col1 - a.col0 + 63) / 64) * (long)((a.row1 - a.row0 + 3) / 4);
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L * 8 ? tiles : 256L * 8);
-    static const int variant = [] {
-        const char *e = getenv("MSSPE_MAIN_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
-    switch (variant) {
-    case 1: hipLaunchKernelGGL((k_pairs_fast<6, 1, 2>), dim3(grid), dim3(256), 0, stream, f); break;
-    case 2: hipLaunchKernelGGL((k_pairs_fast<7, 0, 1>), dim3(grid), dim3(256), 0, stream, f); break;
-    case 3: hipLaunchKernelGGL((k_pairs_fast<4, 3, 2>), dim3(grid), dim3(256), 0, stream, f); break;
-    default:
-        hipLaunchKernelGGL((k_pairs_fast<kNregMain, kNextMain, 2>), dim3(grid), dim3(256), 0, stream, f);
-        break;
-    }
+    hipLaunchKernelGGL((k_pairs_fast<kNregMain, kNextMain, 2>), dim3(grid), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
 
@@ -780,7 +761,6 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
     f.ovf_cap = a.overflow_cap;
     f.in_list = in_list;
     f.in_count = in_count;
-    f.ablate = 0;
     hipLaunchKernelGGL((k_pairs_list<kNregWide, kNextWide>), dim3(256 * 4), dim3(128), 0, stream, f);
     return hipGetLastError();
 }
