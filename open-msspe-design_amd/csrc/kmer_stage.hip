@@ -27,11 +27,17 @@ namespace msspe {
 
 namespace {
 
+// Loop state of the greedy selection, resident on the device so that one iteration is a fixed
+// sequence of launches with constant arguments (hipGraph-replayable, no host round trip).
 struct Status {
-    int maxf;
-    unsigned n_tied;
-    int winner;
-    int pad;
+    int maxf;          // highest live frequency of this iteration
+    unsigned n_tied;   // words tied at maxf
+    int winner;        // id of the selected word
+    int n_win;         // winners recorded so far
+    int stop;          // 1: the loop has ended (every kernel becomes a no-op)
+    int stop_next;     // 1: end after this iteration's push (frequency < max_mismatch_segments)
+    int max_iter;      // --max-iterations
+    int min_freq;      // --max-mismatch-segments
 };
 
 __device__ __forceinline__ int base2(uint8_t c)
@@ -138,20 +144,36 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
     if (i < M) count[i] = (int32_t)(post_off[i + 1] - post_off[i]);
 }
 
-__global__ void k_max_count(const int32_t *count, int M, Status *st)
+__global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
 {
+    __shared__ int part[4];
+    if (st->stop) return;
     int m = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
         m = max(m, count[i]);
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&st->maxf, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic per block: same-address atomics serialise
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m > 0) atomicMax(&st->maxf, m);
+    }
 }
 
-__global__ void k_collect_tied(const int32_t *count, int M, const Status *st, uint32_t *tied,
-                               unsigned *n_tied)
+// main.rs:344-366: end of the loop when no word is left, when the best word is in one segment
+// only, or when max_iterations winners were taken
+__global__ void k_decide(Status *st)
 {
+    if (st->stop) return;
+    if (st->maxf <= 1 || st->n_win >= st->max_iter || st->stop_next) st->stop = 1;
+    st->n_tied = 0;
+}
+
+__global__ void k_collect_tied(const int32_t *count, int M, Status *st, uint32_t *tied)
+{
+    if (st->stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M && count[i] == st->maxf) tied[atomicAdd(n_tied, 1u)] = (uint32_t)i;
+    if (i < M && count[i] == st->maxf) tied[atomicAdd(&st->n_tied, 1u)] = (uint32_t)i;
 }
 
 // partition_tie_score (main.rs:261-283): walk the posting list in ascending segment order, skip
@@ -163,6 +185,7 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const 
                                                     int P, float *score)
 {
     extern __shared__ unsigned char smem[];
+    if (st->stop) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int words = (P + 31) / 32;
     unsigned *seen = (unsigned *)smem + (size_t)wave * words;
@@ -199,11 +222,12 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const 
 
 // winner = highest score, then smallest word (= smallest id: ids follow the sorted key order)
 __global__ void __launch_bounds__(1024) k_pick_winner(const uint32_t *tied, const float *score,
-                                                      Status *st, const uint64_t *ukeys, int it,
+                                                      Status *st, const uint64_t *ukeys,
                                                       uint64_t *out_key, uint32_t *out_freq)
 {
     __shared__ float bs[1024];
     __shared__ uint32_t bk[1024];
+    if (st->stop) return;
     float s = -1.0f;
     uint32_t kid = 0xffffffffu;
     for (unsigned i = threadIdx.x; i < st->n_tied; i += blockDim.x) {
@@ -230,8 +254,10 @@ __global__ void __launch_bounds__(1024) k_pick_winner(const uint32_t *tied, cons
     }
     if (threadIdx.x == 0) {
         st->winner = (int)bk[0];
-        out_key[it] = ukeys[bk[0]];
-        out_freq[it] = (uint32_t)st->maxf;
+        out_key[st->n_win] = ukeys[bk[0]];
+        out_freq[st->n_win] = (uint32_t)st->maxf;
+        st->n_win += 1;
+        if (st->maxf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
     }
 }
 
@@ -240,35 +266,41 @@ __global__ void __launch_bounds__(1024) k_pick_winner(const uint32_t *tied, cons
 // one off the live count of every word they hold.
 __global__ void __launch_bounds__(256) k_cover(const Status *st, const uint32_t *post_off,
                                                const uint32_t *post, uint8_t *ignored,
-                                               uint32_t *coverage, uint32_t *stamp, uint32_t it1,
-                                               int P, int per, const int32_t *kid_of_inst,
-                                               int32_t *count)
+                                               uint32_t *coverage, uint32_t *stamp, int P, int per,
+                                               const int32_t *kid_of_inst, int32_t *count)
 {
+    // one wave per posting: the segment's word ids are read coalesced (lane = window position)
+    if (st->stop) return;
+    const uint32_t it1 = (uint32_t)st->n_win;   // >= 1 here: unique stamp of this iteration
     const uint32_t kid = (uint32_t)st->winner;
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
-    for (uint32_t i = b + blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = b + wave; i < e; i += n_waves) {
         const uint32_t seg = post[i];
-        const uint32_t part = seg % (uint32_t)P;
-        if (atomicExch(&stamp[part], it1) != it1) atomicAdd(&coverage[part], 1u);
-        if (!ignored[seg]) {
+        int was_ignored = 0;
+        if (lane == 0) {
+            const uint32_t part = seg % (uint32_t)P;
+            if (atomicExch(&stamp[part], it1) != it1) atomicAdd(&coverage[part], 1u);
+            was_ignored = ignored[seg];
             ignored[seg] = 1;   // a segment appears once per posting list: no race
-            for (int q = 0; q < per; ++q) {
+        }
+        was_ignored = __shfl(was_ignored, 0);
+        if (!was_ignored)
+            for (int q = lane; q < per; q += 64) {
                 const int32_t k2 = kid_of_inst[(size_t)seg * per + q];
                 if (k2 >= 0) atomicSub(&count[k2], 1);
             }
-        }
     }
 }
 
-__global__ void k_reset_status(Status *st, unsigned *n_tied)
+// last kernel of an iteration: clears the running maximum for the next one
+__global__ void k_next(Status *st)
 {
+    if (st->stop) return;   // keeps the frequency the loop ended on
     st->maxf = 0;
-    st->n_tied = 0;
-    st->winner = -1;
-    *n_tied = 0;
 }
-
-__global__ void k_publish_tied(Status *st, const unsigned *n_tied) { st->n_tied = *n_tied; }
 
 uint64_t lex_to_packed(uint64_t lex, int k)
 {
@@ -364,7 +396,6 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     uint8_t *ignored = (uint8_t *)buf_[11];
     uint32_t *coverage = (uint32_t *)buf_[12], *stamp = coverage + P;
     Status *st = (Status *)buf_[13];
-    unsigned *n_tied = (unsigned *)((char *)buf_[13] + 32);
     uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 64);
     uint32_t *out_freq = (uint32_t *)(out_key + opt.max_iterations);
 
@@ -407,34 +438,66 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     KM_TRY(hipMemsetAsync(coverage, 0, (size_t)P * 8, stream));
     KM_TRY(hipGetLastError());
 
-    // 3. greedy loop
-    const int red_grid = std::min(1024, (M + 255) / 256);
+    // 3. greedy loop: one iteration = six launches with constant arguments, captured once into a
+    //    hipGraph and replayed; the loop state (Status) lives on the device and the host only
+    //    looks at the stop flag every kBatch iterations.
+    const int red_grid = std::min(512, (M + 255) / 256);
     const size_t tie_lds = 4 * sizeof(unsigned) * (size_t)((P + 31) / 32);
-    int n_win = 0;
-    for (int it = 0; it < opt.max_iterations; ++it) {
-        hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(1), 0, stream, st, n_tied);
-        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, stream, count, M, st);
-        Status h;
+    Status h0;
+    std::memset(&h0, 0, sizeof h0);
+    h0.winner = -1;
+    h0.max_iter = std::min(opt.max_iterations, capacity);
+    h0.min_freq = opt.max_mismatch_segments;
+    KM_TRY(hipMemcpyAsync(st, &h0, sizeof h0, hipMemcpyHostToDevice, stream));
+    KM_TRY(hipStreamSynchronize(stream));
+    auto enqueue_iteration = [&](hipStream_t s_) {
+        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, s_, count, M, st);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, s_, st);
+        hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, tied);
+        hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
+                           ignored, coverage, (int)P, score);
+        hipLaunchKernelGGL(k_pick_winner, dim3(1), dim3(1024), 0, s_, tied, score, st, ukeys, out_key,
+                           out_freq);
+        hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
+                           stamp, (int)P, per, kid_of_inst, count);
+        hipLaunchKernelGGL(k_next, dim3(1), dim3(1), 0, s_, st);
+    };
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool use_graph = true;
+    {
+        // capture on a private stream so that the caller's stream may be of any kind
+        hipStream_t cs = nullptr;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) use_graph = false;
+        if (use_graph && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_iteration(cs);
+            if (hipStreamEndCapture(cs, &graph) != hipSuccess || !graph ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                use_graph = false;
+        } else {
+            use_graph = false;
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+        (void)hipGetLastError();
+    }
+    constexpr int kBatch = 32;
+    Status h = h0;
+    for (int done = 0; done < h0.max_iter + 1 && !h.stop; done += kBatch) {
+        for (int b = 0; b < kBatch; ++b) {
+            if (use_graph) KM_TRY(hipGraphLaunch(exec, stream));
+            else enqueue_iteration(stream);
+        }
+        KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
-        if (h.maxf <= 0) break;    // no word left in any live segment (find_most_freq_kmer -> None)
-        if (h.maxf == 1) break;    // main.rs:354-360: a single shared window, stop before the push
-        if (n_win >= capacity) {
-            err = "stage A: more winners than the caller's capacity";
-            return MSSPE_ERR_CAPACITY;
-        }
-        hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, stream, count, M, st,
-                           tied, n_tied);
-        hipLaunchKernelGGL(k_publish_tied, dim3(1), dim3(1), 0, stream, st, n_tied);
-        hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, stream, tied, st, post_off, post,
-                           ignored, coverage, (int)P, score);
-        hipLaunchKernelGGL(k_pick_winner, dim3(1), dim3(1024), 0, stream, tied, score, st, ukeys, n_win,
-                           out_key, out_freq);
-        hipLaunchKernelGGL(k_cover, dim3(64), dim3(256), 0, stream, st, post_off, post, ignored, coverage,
-                           stamp, (uint32_t)(it + 1), (int)P, per, kid_of_inst, count);
-        KM_TRY(hipGetLastError());
-        ++n_win;
-        if (h.maxf < opt.max_mismatch_segments) break;   // main.rs:387-390: stop after the push
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    const int n_win = h.n_win;
+    if (n_win >= capacity && !h.stop_next && h.maxf > 1 && capacity < opt.max_iterations) {
+        // the caller's buffers ended the loop, not the reference's rules
+        err = "stage A: more winners than the caller's capacity";
+        return MSSPE_ERR_CAPACITY;
     }
     if (n_win) {
         std::vector<uint64_t> hk((size_t)n_win);
