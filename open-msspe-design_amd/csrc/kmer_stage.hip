@@ -38,6 +38,9 @@ struct Status {
     int stop_next;     // 1: end after this iteration's push (frequency < max_mismatch_segments)
     int max_iter;      // --max-iterations
     int min_freq;      // --max-mismatch-segments
+    unsigned n_long;   // tied words with a long posting list (kept at the back of `tied`)
+    unsigned ticket;   // last-block detection
+    unsigned long long best;   // winner_key() maximum over the tied words
 };
 
 __device__ __forceinline__ int base2(uint8_t c)
@@ -144,6 +147,13 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
     if (i < M) count[i] = (int32_t)(post_off[i + 1] - post_off[i]);
 }
 
+// ---- greedy loop -------------------------------------------------------------------------------
+// One iteration = k_max_count -> k_collect_tied -> k_tie_scores + k_tie_long -> k_cover, all with
+// constant arguments.  Single-thread bookkeeping rides on the last block of k_max_count (decide)
+// and of k_cover (record the winner), found with a ticket counter.
+
+constexpr unsigned kLongList = 512;   // posting lists above this get a whole block in k_tie_long
+
 __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
 {
     __shared__ int part[4];
@@ -157,32 +167,60 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
     if (threadIdx.x == 0) {   // one atomic per block: same-address atomics serialise
         m = max(max(part[0], part[1]), max(part[2], part[3]));
         if (m > 0) atomicMax(&st->maxf, m);
+        __threadfence();
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            // last block: the maximum is final.  main.rs:344-366: the loop ends when no word is
+            // left, when the best word is in one segment only, or after max_iterations winners
+            const int mf = atomicMax(&st->maxf, 0);
+            if (mf <= 1 || st->n_win >= st->max_iter || st->stop_next) st->stop = 1;
+            st->n_tied = 0;
+            st->n_long = 0;
+            st->ticket = 0;
+        }
     }
 }
 
-// main.rs:344-366: end of the loop when no word is left, when the best word is in one segment
-// only, or when max_iterations winners were taken
-__global__ void k_decide(Status *st)
-{
-    if (st->stop) return;
-    if (st->maxf <= 1 || st->n_win >= st->max_iter || st->stop_next) st->stop = 1;
-    st->n_tied = 0;
-}
-
-__global__ void k_collect_tied(const int32_t *count, int M, Status *st, uint32_t *tied)
+// Words tied at the maximum: short posting lists go to the front of `tied`, long ones to the back
+// (slot M-1-j).  Wave-aggregated so that a million-way tie costs thousands of atomics, not millions.
+__global__ void __launch_bounds__(256) k_collect_tied(const int32_t *count, int M, Status *st,
+                                                      const uint32_t *post_off, uint32_t *tied)
 {
     if (st->stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M && count[i] == st->maxf) tied[atomicAdd(&st->n_tied, 1u)] = (uint32_t)i;
+    const int lane = threadIdx.x & 63;
+    const bool hit = i < M && count[i] == st->maxf;
+    const bool is_long = hit && post_off[i + 1] - post_off[i] > kLongList;
+    const unsigned long long ms = __ballot(hit && !is_long), ml = __ballot(is_long);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (ms) {
+        unsigned base = 0;
+        if (lane == __ffsll((long long)ms) - 1) base = atomicAdd(&st->n_tied, (unsigned)__popcll(ms));
+        base = __shfl(base, __ffsll((long long)ms) - 1);
+        if (hit && !is_long) tied[base + (unsigned)__popcll(ms & below)] = (uint32_t)i;
+    }
+    if (ml) {
+        unsigned base = 0;
+        if (lane == __ffsll((long long)ml) - 1) base = atomicAdd(&st->n_long, (unsigned)__popcll(ml));
+        base = __shfl(base, __ffsll((long long)ml) - 1);
+        if (is_long) tied[(unsigned)M - 1u - (base + (unsigned)__popcll(ml & below))] = (uint32_t)i;
+    }
+}
+
+// winner = highest score, then smallest word (= smallest id: ids follow the sorted key order).
+// Scores are positive f32, so their bit patterns order like the values.
+__device__ __forceinline__ unsigned long long winner_key(float score, uint32_t kid)
+{
+    return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xffffffffu - kid);
 }
 
 // partition_tie_score (main.rs:261-283): walk the posting list in ascending segment order, skip
-// covered segments, and on the first sight of each partition add 1 / (coverage + 1) in f32.
-// One wave per tied word; `seen` is a per-wave bitmap in LDS.
-__global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const Status *st,
+// covered segments, and on the first sight of each partition add 1 / (coverage + 1) in f32 (the
+// order of the additions is the reference's).  One wave per tied word; `seen` is a per-wave bitmap
+// in LDS.
+__global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status *st,
                                                     const uint32_t *post_off, const uint32_t *post,
                                                     const uint8_t *ignored, const uint32_t *coverage,
-                                                    int P, float *score)
+                                                    int P)
 {
     extern __shared__ unsigned char smem[];
     if (st->stop) return;
@@ -190,6 +228,7 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const 
     const int words = (P + 31) / 32;
     unsigned *seen = (unsigned *)smem + (size_t)wave * words;
     const unsigned n = st->n_tied;
+    unsigned long long best = 0;
     for (unsigned tix = blockIdx.x * 4 + wave; tix < n; tix += gridDim.x * 4) {
         for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
         const uint32_t kid = tied[tix];
@@ -198,108 +237,158 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, const 
         for (uint32_t base = b; base < e; base += 64) {
             const uint32_t i = base + lane;
             bool fresh = false;
-            int part = 0;
+            int part = -1;
             if (i < e) {
                 const uint32_t seg = post[i];
                 part = (int)(seg % (uint32_t)P);
                 fresh = !ignored[seg] && !((seen[part >> 5] >> (part & 31)) & 1u);
             }
             unsigned long long m = __ballot(fresh);
-            while (m) {   // wave-uniform: candidates in ascending posting order
+            while (m) {   // wave-uniform: distinct new partitions in ascending posting order
                 const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
                 const int pl = __shfl(part, l);
-                const unsigned wdv = seen[pl >> 5];
-                if (!((wdv >> (pl & 31)) & 1u)) {
-                    if (lane == 0) seen[pl >> 5] = wdv | (1u << (pl & 31));
-                    acc += 1.0f / ((float)coverage[pl] + 1.0f);
+                m &= ~__ballot(part == pl);
+                if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+                acc += 1.0f / ((float)coverage[pl] + 1.0f);
+            }
+        }
+        const unsigned long long key = winner_key(acc, kid);
+        best = key > best ? key : best;
+    }
+    if (lane == 0 && best) atomicMax(&st->best, best);
+}
+
+// The same walk for a long posting list, one 1024-thread block per word: the block loads and
+// filters 1024 postings at a time; only chunks that hold a not-yet-seen partition (normally just
+// the first) take the ordered path, where the 16 waves resolve their candidates in turn.
+__global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, Status *st,
+                                                   const uint32_t *post_off, const uint32_t *post,
+                                                   const uint8_t *ignored, const uint32_t *coverage,
+                                                   int P)
+{
+    extern __shared__ unsigned char smem[];
+    __shared__ float acc_s;
+    if (st->stop) return;
+    unsigned *seen = (unsigned *)smem;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int words = (P + 31) / 32;
+    const unsigned n = st->n_long;
+    for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
+        for (int wd = threadIdx.x; wd < words; wd += blockDim.x) seen[wd] = 0u;
+        if (threadIdx.x == 0) acc_s = 0.0f;
+        const uint32_t kid = tied[(unsigned)M - 1u - j];
+        const uint32_t b = post_off[kid], e = post_off[kid + 1];
+        // one chunk of look-ahead on the (post -> ignored) dependent loads
+        uint32_t seg_n = 0;
+        bool live_n = false;
+        if (b + threadIdx.x < e) {
+            seg_n = post[b + threadIdx.x];
+            live_n = !ignored[seg_n];
+        }
+        __syncthreads();
+        for (uint32_t base = b; base < e; base += 1024) {
+            const uint32_t seg = seg_n;
+            const bool live = live_n;
+            const uint32_t in = base + 1024 + threadIdx.x;
+            live_n = false;
+            if (in < e) {
+                seg_n = post[in];
+                live_n = !ignored[seg_n];
+            }
+            const int part = live ? (int)(seg % (uint32_t)P) : -1;
+            const int ps = live ? part : 0;   // in-bounds bitmap index for idle lanes
+            bool fresh = live && !((seen[ps >> 5] >> (ps & 31)) & 1u);
+            if (__syncthreads_or(fresh)) {
+                for (int w = 0; w < 16; ++w) {
+                    if (wave == w) {
+                        // partitions taken by the earlier waves of this chunk are visible now
+                        if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
+                        unsigned long long m = __ballot(fresh);
+                        float acc = acc_s;
+                        while (m) {
+                            const int l = __ffsll((long long)m) - 1;
+                            const int pl = __shfl(part, l);
+                            m &= ~__ballot(part == pl);
+                            if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+                            acc += 1.0f / ((float)coverage[pl] + 1.0f);
+                        }
+                        if (lane == 0) acc_s = acc;
+                    }
+                    __syncthreads();
                 }
             }
         }
-        if (lane == 0) score[tix] = acc;
-    }
-}
-
-// winner = highest score, then smallest word (= smallest id: ids follow the sorted key order)
-__global__ void __launch_bounds__(1024) k_pick_winner(const uint32_t *tied, const float *score,
-                                                      Status *st, const uint64_t *ukeys,
-                                                      uint64_t *out_key, uint32_t *out_freq)
-{
-    __shared__ float bs[1024];
-    __shared__ uint32_t bk[1024];
-    if (st->stop) return;
-    float s = -1.0f;
-    uint32_t kid = 0xffffffffu;
-    for (unsigned i = threadIdx.x; i < st->n_tied; i += blockDim.x) {
-        const float si = score[i];
-        const uint32_t ki = tied[i];
-        if (si > s || (si == s && ki < kid)) {
-            s = si;
-            kid = ki;
-        }
-    }
-    bs[threadIdx.x] = s;
-    bk[threadIdx.x] = kid;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            const float so = bs[threadIdx.x + off];
-            const uint32_t ko = bk[threadIdx.x + off];
-            if (so > bs[threadIdx.x] || (so == bs[threadIdx.x] && ko < bk[threadIdx.x])) {
-                bs[threadIdx.x] = so;
-                bk[threadIdx.x] = ko;
-            }
-        }
+        if (threadIdx.x == 0) atomicMax(&st->best, winner_key(acc_s, kid));
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        st->winner = (int)bk[0];
-        out_key[st->n_win] = ukeys[bk[0]];
-        out_freq[st->n_win] = (uint32_t)st->maxf;
-        st->n_win += 1;
-        if (st->maxf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
     }
 }
 
 // Cover every segment that holds the winner: bump the partition coverage once per distinct
 // partition (main.rs:371-378, covered segments included) and, for segments covered now, take
-// one off the live count of every word they hold.
-__global__ void __launch_bounds__(256) k_cover(const Status *st, const uint32_t *post_off,
+// one off the live count of every word they hold.  Lane = posting; neighbouring postings are the
+// same window of near-identical genomes, so equal targets are merged across the wave before the
+// atomic (same-address atomics serialise in L2).  The last block records the winner.
+__global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_off,
                                                const uint32_t *post, uint8_t *ignored,
                                                uint32_t *coverage, uint32_t *stamp, int P, int per,
-                                               const int32_t *kid_of_inst, int32_t *count)
+                                               const int32_t *kid_of_inst, int32_t *count,
+                                               const uint64_t *ukeys, uint64_t *out_key,
+                                               uint32_t *out_freq)
 {
-    // one wave per posting: the segment's word ids are read coalesced (lane = window position)
     if (st->stop) return;
-    const uint32_t it1 = (uint32_t)st->n_win;   // >= 1 here: unique stamp of this iteration
-    const uint32_t kid = (uint32_t)st->winner;
+    const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
+    const uint32_t kid = 0xffffffffu - (uint32_t)(st->best & 0xffffffffull);
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t i = b + wave; i < e; i += n_waves) {
-        const uint32_t seg = post[i];
-        int was_ignored = 0;
-        if (lane == 0) {
-            const uint32_t part = seg % (uint32_t)P;
-            if (atomicExch(&stamp[part], it1) != it1) atomicAdd(&coverage[part], 1u);
-            was_ignored = ignored[seg];
+    for (uint32_t base = b + wave * 64u; base < e; base += n_waves * 64u) {
+        const uint32_t i = base + lane;
+        uint32_t seg = 0;
+        int part = -1;
+        bool live = false;
+        if (i < e) {
+            seg = post[i];
+            part = (int)(seg % (uint32_t)P);
+            live = !ignored[seg];
             ignored[seg] = 1;   // a segment appears once per posting list: no race
         }
-        was_ignored = __shfl(was_ignored, 0);
-        if (!was_ignored)
-            for (int q = lane; q < per; q += 64) {
-                const int32_t k2 = kid_of_inst[(size_t)seg * per + q];
-                if (k2 >= 0) atomicSub(&count[k2], 1);
+        unsigned long long m = __ballot(part >= 0);
+        while (m) {   // once per distinct partition of the wave
+            const int l = __ffsll((long long)m) - 1;
+            const int pl = __shfl(part, l);
+            m &= ~__ballot(part == pl);
+            if (lane == l && atomicExch(&stamp[pl], it1) != it1) atomicAdd(&coverage[pl], 1u);
+        }
+        if (!__ballot(live)) continue;
+        const int32_t *row = kid_of_inst + (size_t)seg * per;
+        for (int q = 0; q < per; ++q) {
+            const int32_t k2 = live ? row[q] : -1;
+            unsigned long long mk = __ballot(k2 >= 0);
+            while (mk) {   // once per distinct word at this window position
+                const int l = __ffsll((long long)mk) - 1;
+                const int32_t kl = __shfl(k2, l);
+                const unsigned long long same = __ballot(k2 == kl);
+                if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
+                mk &= ~same;
             }
+        }
     }
-}
-
-// last kernel of an iteration: clears the running maximum for the next one
-__global__ void k_next(Status *st)
-{
-    if (st->stop) return;   // keeps the frequency the loop ended on
-    st->maxf = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            const int mf = st->maxf;
+            out_key[st->n_win] = ukeys[kid];
+            out_freq[st->n_win] = (uint32_t)mf;
+            st->winner = (int)kid;
+            st->n_win += 1;
+            if (mf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
+            st->maxf = 0;
+            st->best = 0;
+            st->ticket = 0;
+        }
+    }
 }
 
 uint64_t lex_to_packed(uint64_t lex, int k)
@@ -374,13 +463,13 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     const uint64_t sentinel = 1ull << (2 * k);
     int rc;
     // buffers: 0/1 keys, 2/3 vals, 4 head, 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
-    // 10 count+tied+score, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp
+    // 10 count+tied, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp
     if ((rc = ensure(0, n_inst * 8, err)) || (rc = ensure(1, n_inst * 8, err)) ||
         (rc = ensure(2, n_inst * 4, err)) || (rc = ensure(3, n_inst * 4, err)) ||
         (rc = ensure(4, n_inst * 4, err)) || (rc = ensure(5, n_inst * 4, err)) ||
         (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
-        (rc = ensure(10, n_inst * 12, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
+        (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
         (rc = ensure(12, (size_t)P * 8, err)) ||
         (rc = ensure(13, 64 + (size_t)opt.max_iterations * 12, err)))
         return rc;
@@ -392,7 +481,6 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     uint64_t *ukeys = (uint64_t *)buf_[9];
     int32_t *count = (int32_t *)buf_[10];
     uint32_t *tied = (uint32_t *)buf_[10] + n_inst;
-    float *score = (float *)buf_[10] + 2 * n_inst;
     uint8_t *ignored = (uint8_t *)buf_[11];
     uint32_t *coverage = (uint32_t *)buf_[12], *stamp = coverage + P;
     Status *st = (Status *)buf_[13];
@@ -438,7 +526,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     KM_TRY(hipMemsetAsync(coverage, 0, (size_t)P * 8, stream));
     KM_TRY(hipGetLastError());
 
-    // 3. greedy loop: one iteration = six launches with constant arguments, captured once into a
+    // 3. greedy loop: one iteration = five launches with constant arguments, captured once into a
     //    hipGraph and replayed; the loop state (Status) lives on the device and the host only
     //    looks at the stop flag every kBatch iterations.
     const int red_grid = std::min(512, (M + 255) / 256);
@@ -452,15 +540,14 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     KM_TRY(hipStreamSynchronize(stream));
     auto enqueue_iteration = [&](hipStream_t s_) {
         hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, s_, count, M, st);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, s_, st);
-        hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, tied);
+        hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
+                           post_off, tied);
         hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
-                           ignored, coverage, (int)P, score);
-        hipLaunchKernelGGL(k_pick_winner, dim3(1), dim3(1024), 0, s_, tied, score, st, ukeys, out_key,
-                           out_freq);
+                           ignored, coverage, (int)P);
+        hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
+                           post, ignored, coverage, (int)P);
         hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, per, kid_of_inst, count);
-        hipLaunchKernelGGL(k_next, dim3(1), dim3(1), 0, s_, st);
+                           stamp, (int)P, per, kid_of_inst, count, ukeys, out_key, out_freq);
     };
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -494,7 +581,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     if (exec) (void)hipGraphExecDestroy(exec);
     if (graph) (void)hipGraphDestroy(graph);
     const int n_win = h.n_win;
-    if (n_win >= capacity && !h.stop_next && h.maxf > 1 && capacity < opt.max_iterations) {
+    if (h.maxf > 1 && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
         // the caller's buffers ended the loop, not the reference's rules
         err = "stage A: more winners than the caller's capacity";
         return MSSPE_ERR_CAPACITY;

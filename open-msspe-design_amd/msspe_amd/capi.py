@@ -241,9 +241,10 @@ class Engine:
     # ---- stage A ---------------------------------------------------------------------------
     def kmer_candidates(self, seqs: np.ndarray, opt: KmerOpt, direction: int,
                         device_ptr: int | None = None, n_seq: int | None = None,
-                        seq_len: int | None = None):
-        """seqs: uint8 (n_seq, L) host array (or pass device_ptr + shape).  Returns (words, freqs)."""
-        cap = max(1, opt.max_iterations)
+                        seq_len: int | None = None, capacity: int | None = None):
+        """seqs: uint8 (n_seq, L) host array (or pass device_ptr + shape).  Returns (words, freqs).
+        capacity: size of the output buffers (default: max_iterations, which always suffices)."""
+        cap = max(1, opt.max_iterations if capacity is None else capacity)
         words = np.zeros(cap, dtype=np.uint64)
         freqs = np.zeros(cap, dtype=np.uint32)
         n_out = C.c_int(0)

@@ -72,6 +72,38 @@ def test_small_parameters_and_ties(eng, m, oracle):
     run_both(eng, m, oracle, seqs, seg=60, stride=30, win=30, k=8, iters=1000, mm=4)
 
 
+def test_long_posting_lists_and_ties(eng, m, oracle):
+    """700 near-identical rows: posting lists of thousands of segments spread over many partitions
+    (k = 3) tie at the same frequency, so the block-per-word scoring kernel, its ordered path and
+    the wave-merged count updates all decide winners here."""
+    rng = np.random.default_rng(11)
+    anc = rng.integers(0, 4, 400)
+    seqs = []
+    for r in range(700):
+        row = anc.copy()
+        mut = rng.random(400) < (0.002 if r % 3 else 0.03)
+        row[mut] = rng.integers(0, 4, int(mut.sum()))
+        seqs.append("".join("ACGT"[x] for x in row))
+    run_both(eng, m, oracle, seqs, seg=40, stride=20, win=12, k=3, iters=1000, mm=1)
+    run_both(eng, m, oracle, seqs, seg=60, stride=30, win=30, k=8, iters=1000, mm=20)
+    run_both(eng, m, oracle, seqs, seg=100, stride=50, win=50, k=13, iters=50, mm=1)
+
+
+def test_output_capacity(eng, m, oracle):
+    """The loop state lives on the device; a caller buffer that is too small is an error, one that
+    is exactly large enough is not."""
+    genomes = m.synth.aligned_genomes(40, 6000)
+    opt = m.KmerOpt(500, 250, 50, 13, 1000, 1)
+    words, freqs = eng.kmer_candidates(genomes, opt, 0)
+    assert len(words) > 8
+    w2, f2 = eng.kmer_candidates(genomes, opt, 0, capacity=len(words))
+    assert (w2, f2.tolist()) == (words, freqs.tolist())
+    with pytest.raises(m.MsspeError):
+        eng.kmer_candidates(genomes, opt, 0, capacity=len(words) - 1)
+    w3, f3 = eng.kmer_candidates(genomes, m.KmerOpt(500, 250, 50, 13, 5, 1), 0, capacity=5)
+    assert (w3, f3.tolist()) == (words[:5], freqs[:5].tolist())
+
+
 def test_edge_inputs(eng, m, oracle):
     opt = m.KmerOpt(500, 250, 50, 13, 1000, 1)
     short = np.frombuffer(("ACGT" * 100).encode(), dtype=np.uint8).reshape(1, -1)   # < one segment
