@@ -43,6 +43,15 @@ struct Status {
     unsigned long long best;   // winner_key() maximum over the tied words
 };
 
+// Segment ids are genome-major (seg = genome * P + partition: the order the reference walks
+// them in), but a winner's postings are mostly one partition of many genomes.  The per-segment
+// tables the cover step gathers from (word ids, covered flags) are therefore stored
+// partition-major, so that those rows are neighbours in memory (same pages, same cache lines).
+__device__ __forceinline__ uint32_t row_of(uint32_t seg, uint32_t P, uint32_t G)
+{
+    return (seg % P) * G + seg / P;
+}
+
 __device__ __forceinline__ int base2(uint8_t c)
 {
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
@@ -109,20 +118,22 @@ __global__ void k_heads(const uint64_t *key, size_t n, uint64_t sentinel, uint32
 }
 
 __global__ void k_index(const uint64_t *key, const uint32_t *val, const uint32_t *head,
-                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per,
+                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G,
                         int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = key[i];
     const uint32_t inst = val[i];
+    const uint32_t seg = inst / (uint32_t)per, q = inst % (uint32_t)per;
+    const size_t slot = (size_t)row_of(seg, (uint32_t)P, (uint32_t)G) * per + q;
     if (k == sentinel) {
-        kid_of_inst[inst] = -1;
+        kid_of_inst[slot] = -1;
         return;
     }
     const uint32_t kid = hscan[i] + head[i] - 1;
-    kid_of_inst[inst] = (int32_t)kid;
-    post[i] = inst / (uint32_t)per;
+    kid_of_inst[slot] = (int32_t)kid;
+    post[i] = seg;
     if (head[i]) {
         post_off[kid] = (uint32_t)i;
         ukeys[kid] = k;
@@ -152,7 +163,8 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
 // constant arguments.  Single-thread bookkeeping rides on the last block of k_max_count (decide)
 // and of k_cover (record the winner), found with a ticket counter.
 
-constexpr unsigned kLongList = 512;   // posting lists above this get a whole block in k_tie_long
+constexpr unsigned kLongList = 512;
+constexpr int kTieUnroll = 4;        // 1024-posting chunks whose loads k_tie_long keeps in flight   // posting lists above this get a whole block in k_tie_long
 
 __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
 {
@@ -220,7 +232,7 @@ __device__ __forceinline__ unsigned long long winner_key(float score, uint32_t k
 __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status *st,
                                                     const uint32_t *post_off, const uint32_t *post,
                                                     const uint8_t *ignored, const uint32_t *coverage,
-                                                    int P)
+                                                    int P, int G)
 {
     extern __shared__ unsigned char smem[];
     if (st->stop) return;
@@ -228,6 +240,10 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
     const int words = (P + 31) / 32;
     unsigned *seen = (unsigned *)smem + (size_t)wave * words;
     const unsigned n = st->n_tied;
+    if (n + st->n_long == 1) {   // a single candidate wins whatever its score
+        if (n == 1 && blockIdx.x == 0 && threadIdx.x == 0) st->best = winner_key(1.0f, tied[0]);
+        return;
+    }
     unsigned long long best = 0;
     for (unsigned tix = blockIdx.x * 4 + wave; tix < n; tix += gridDim.x * 4) {
         for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
@@ -241,7 +257,8 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
             if (i < e) {
                 const uint32_t seg = post[i];
                 part = (int)(seg % (uint32_t)P);
-                fresh = !ignored[seg] && !((seen[part >> 5] >> (part & 31)) & 1u);
+                fresh = !ignored[(uint32_t)part * (uint32_t)G + seg / (uint32_t)P] &&
+                        !((seen[part >> 5] >> (part & 31)) & 1u);
             }
             unsigned long long m = __ballot(fresh);
             while (m) {   // wave-uniform: distinct new partitions in ascending posting order
@@ -264,7 +281,7 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
 __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, Status *st,
                                                    const uint32_t *post_off, const uint32_t *post,
                                                    const uint8_t *ignored, const uint32_t *coverage,
-                                                   int P)
+                                                   int P, int G)
 {
     extern __shared__ unsigned char smem[];
     __shared__ float acc_s;
@@ -273,48 +290,52 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int words = (P + 31) / 32;
     const unsigned n = st->n_long;
+    if (n + st->n_tied == 1) {   // a single candidate wins whatever its score
+        if (n == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+            st->best = winner_key(1.0f, tied[(unsigned)M - 1u]);
+        return;
+    }
     for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
         for (int wd = threadIdx.x; wd < words; wd += blockDim.x) seen[wd] = 0u;
         if (threadIdx.x == 0) acc_s = 0.0f;
         const uint32_t kid = tied[(unsigned)M - 1u - j];
         const uint32_t b = post_off[kid], e = post_off[kid + 1];
-        // one chunk of look-ahead on the (post -> ignored) dependent loads
-        uint32_t seg_n = 0;
-        bool live_n = false;
-        if (b + threadIdx.x < e) {
-            seg_n = post[b + threadIdx.x];
-            live_n = !ignored[seg_n];
-        }
         __syncthreads();
-        for (uint32_t base = b; base < e; base += 1024) {
-            const uint32_t seg = seg_n;
-            const bool live = live_n;
-            const uint32_t in = base + 1024 + threadIdx.x;
-            live_n = false;
-            if (in < e) {
-                seg_n = post[in];
-                live_n = !ignored[seg_n];
+        for (uint32_t base = b; base < e; base += 1024 * kTieUnroll) {
+            // kTieUnroll chunks of (post -> ignored) dependent loads in flight at once
+            uint32_t seg[kTieUnroll];
+            bool live[kTieUnroll];
+#pragma unroll
+            for (int u = 0; u < kTieUnroll; ++u) {
+                const uint32_t i = base + u * 1024 + threadIdx.x;
+                seg[u] = i < e ? post[i] : 0xffffffffu;
             }
-            const int part = live ? (int)(seg % (uint32_t)P) : -1;
-            const int ps = live ? part : 0;   // in-bounds bitmap index for idle lanes
-            bool fresh = live && !((seen[ps >> 5] >> (ps & 31)) & 1u);
-            if (__syncthreads_or(fresh)) {
-                for (int w = 0; w < 16; ++w) {
-                    if (wave == w) {
-                        // partitions taken by the earlier waves of this chunk are visible now
-                        if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
-                        unsigned long long m = __ballot(fresh);
-                        float acc = acc_s;
-                        while (m) {
-                            const int l = __ffsll((long long)m) - 1;
-                            const int pl = __shfl(part, l);
-                            m &= ~__ballot(part == pl);
-                            if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
-                            acc += 1.0f / ((float)coverage[pl] + 1.0f);
+#pragma unroll
+            for (int u = 0; u < kTieUnroll; ++u)
+                live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
+#pragma unroll
+            for (int u = 0; u < kTieUnroll; ++u) {
+                const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
+                const int ps = live[u] ? part : 0;   // in-bounds bitmap index for idle lanes
+                bool fresh = live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u);
+                if (__syncthreads_or(fresh)) {
+                    for (int w = 0; w < 16; ++w) {
+                        if (wave == w) {
+                            // partitions taken by the earlier waves of this chunk are visible now
+                            if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
+                            unsigned long long m = __ballot(fresh);
+                            float acc = acc_s;
+                            while (m) {
+                                const int l = __ffsll((long long)m) - 1;
+                                const int pl = __shfl(part, l);
+                                m &= ~__ballot(part == pl);
+                                if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+                                acc += 1.0f / ((float)coverage[pl] + 1.0f);
+                            }
+                            if (lane == 0) acc_s = acc;
                         }
-                        if (lane == 0) acc_s = acc;
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
             }
         }
@@ -325,54 +346,87 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
 
 // Cover every segment that holds the winner: bump the partition coverage once per distinct
 // partition (main.rs:371-378, covered segments included) and, for segments covered now, take
-// one off the live count of every word they hold.  Lane = posting; neighbouring postings are the
-// same window of near-identical genomes, so equal targets are merged across the wave before the
-// atomic (same-address atomics serialise in L2).  The last block records the winner.
+// one off the live count of every word they hold.
+// A block takes 64 postings at a time.  Wave 0 does the per-posting bookkeeping; the four waves
+// then gather the 64 segments' word ids into an LDS tile (32 window positions per pass, 128-byte
+// half-row loads) and split the window positions between them with lane = posting: neighbouring
+// postings are the same window of near-identical genomes, so equal targets are merged across the
+// wave before the atomic (same-address atomics serialise in L2).  The last block records the
+// winner.
 __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_off,
                                                const uint32_t *post, uint8_t *ignored,
-                                               uint32_t *coverage, uint32_t *stamp, int P, int per,
-                                               const int32_t *kid_of_inst, int32_t *count,
+                                               uint32_t *coverage, uint32_t *stamp, int P, int G,
+                                               int per, const int32_t *kid_of_inst, int32_t *count,
                                                const uint64_t *ukeys, uint64_t *out_key,
                                                uint32_t *out_freq)
 {
+    __shared__ int32_t tile[64 * 33];
+    __shared__ uint32_t rows_s[64];   // partition-major row of each posting, ~0u: nothing to do
+    __shared__ int any_live;
     if (st->stop) return;
     const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
     const uint32_t kid = 0xffffffffu - (uint32_t)(st->best & 0xffffffffull);
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t base = b + wave * 64u; base < e; base += n_waves * 64u) {
-        const uint32_t i = base + lane;
-        uint32_t seg = 0;
-        int part = -1;
-        bool live = false;
-        if (i < e) {
-            seg = post[i];
-            part = (int)(seg % (uint32_t)P);
-            live = !ignored[seg];
-            ignored[seg] = 1;   // a segment appears once per posting list: no race
-        }
-        unsigned long long m = __ballot(part >= 0);
-        while (m) {   // once per distinct partition of the wave
-            const int l = __ffsll((long long)m) - 1;
-            const int pl = __shfl(part, l);
-            m &= ~__ballot(part == pl);
-            if (lane == l && atomicExch(&stamp[pl], it1) != it1) atomicAdd(&coverage[pl], 1u);
-        }
-        if (!__ballot(live)) continue;
-        const int32_t *row = kid_of_inst + (size_t)seg * per;
-        for (int q = 0; q < per; ++q) {
-            const int32_t k2 = live ? row[q] : -1;
-            unsigned long long mk = __ballot(k2 >= 0);
-            while (mk) {   // once per distinct word at this window position
-                const int l = __ffsll((long long)mk) - 1;
-                const int32_t kl = __shfl(k2, l);
-                const unsigned long long same = __ballot(k2 == kl);
-                if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
-                mk &= ~same;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
+        if (wave == 0) {
+            const uint32_t i = base + lane;
+            uint32_t row = 0;
+            int part = -1;
+            bool live = false;
+            if (i < e) {
+                const uint32_t seg = post[i];
+                part = (int)(seg % (uint32_t)P);
+                row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
+                live = !ignored[row];
+                ignored[row] = 1;   // a segment appears once per posting list: no race
+            }
+            rows_s[lane] = live ? row : 0xffffffffu;
+            const unsigned long long lives = __ballot(live);
+            if (lane == 0) any_live = lives != 0ull;
+            unsigned long long m = __ballot(part >= 0);
+            while (m) {   // once per distinct partition of the wave
+                const int l = __ffsll((long long)m) - 1;
+                const int pl = __builtin_amdgcn_readlane(part, l);
+                m &= ~__ballot(part == pl);
+                if (lane == l && atomicExch(&stamp[pl], it1) != it1) atomicAdd(&coverage[pl], 1u);
             }
         }
+        __syncthreads();
+        if (any_live) {
+            for (int q0 = 0; q0 < per; q0 += 32) {
+                int32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {   // 8 loads per thread in flight before the LDS stores
+                    const int r = 8 * j + (threadIdx.x >> 5), q = q0 + (threadIdx.x & 31);
+                    const uint32_t row_r = rows_s[r];
+                    const bool ok = row_r != 0xffffffffu && q < per;
+                    const int32_t x = kid_of_inst[ok ? (size_t)row_r * per + q : 0];
+                    v[j] = ok ? x : -1;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    tile[(8 * j + (threadIdx.x >> 5)) * 33 + (threadIdx.x & 31)] = v[j];
+                __syncthreads();
+                const int nq = min(32, per - q0);
+                for (int qq = wave; qq < nq; qq += 4) {
+                    const int32_t k2 = tile[lane * 33 + qq];
+                    // merge the common words of this window position (up to three rounds: the
+                    // consensus word and its most frequent variants), the rest go one by one
+                    unsigned long long mk = __ballot(k2 >= 0);
+                    for (int round = 0; round < 3 && mk; ++round) {
+                        const int l = __ffsll((long long)mk) - 1;
+                        const int32_t kl = __builtin_amdgcn_readlane(k2, l);
+                        const unsigned long long same = __ballot(k2 == kl);
+                        if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
+                        mk &= ~same;
+                    }
+                    if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();   // rows_s / any_live are rewritten by the next group
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -518,7 +572,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     if (M == 0) return MSSPE_OK;
     // number of valid instances = first sentinel position: post_off[M]
     hipLaunchKernelGGL(k_index, dim3(g_inst), dim3(256), 0, stream, key_b, val_b, head, hscan, n_inst,
-                       sentinel, per, kid_of_inst, post, post_off, ukeys);
+                       sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys);
     // post_off[M] = number of non-sentinel instances (sentinels sort last)
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, stream, key_b, n_inst, sentinel, post_off, M);
     hipLaunchKernelGGL(k_init_counts, dim3((M + 255) / 256), dim3(256), 0, stream, post_off, M, count);
@@ -529,7 +583,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     // 3. greedy loop: one iteration = five launches with constant arguments, captured once into a
     //    hipGraph and replayed; the loop state (Status) lives on the device and the host only
     //    looks at the stop flag every kBatch iterations.
-    const int red_grid = std::min(512, (M + 255) / 256);
+    const int red_grid = std::min(128, (M + 255) / 256);
     const size_t tie_lds = 4 * sizeof(unsigned) * (size_t)((P + 31) / 32);
     Status h0;
     std::memset(&h0, 0, sizeof h0);
@@ -543,11 +597,11 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
         hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
                            post_off, tied);
         hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
-                           ignored, coverage, (int)P);
+                           ignored, coverage, (int)P, n_seq);
         hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
-                           post, ignored, coverage, (int)P);
+                           post, ignored, coverage, (int)P, n_seq);
         hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, per, kid_of_inst, count, ukeys, out_key, out_freq);
+                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq);
     };
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
