@@ -111,6 +111,24 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
  * DP did not fit the fast kernel's register-resident table. */
 int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
 
+/* Diagnostics of the exact-integer first stage of the cross-dimer path since the last call
+ * (engine-only, no reference counterpart): out[0] = pairs it handed to the f64 kernels because
+ * Primer3's double comparisons could go either way, out[1..6] = how many of them met each reason
+ * (Tm near-tie, loop == stack/start value, tie between loops, rejected minimum, tie in the
+ * terminal pick, replay mismatch); out[7] = samples kept.  Reading resets the counters. */
+int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8]);
+/* Up to 1024 of those pairs (call before msspe_pair_stage_stats, which resets the sample count):
+ * out[i] = row << 40 | col << 16 | reason bits (1 Tm, 2 loop == value, 4 loop tie, 8 rejected
+ * minimum, 16 pick tie, 32 replay). */
+int msspe_pair_stage_samples(msspe_ctx *ctx, uint64_t *out, int capacity, int *n_out);
+/* Host only, no device: the folded tables the all-pairs kernels keep in LDS (csrc/fast_tables.hpp),
+ * so that CPU tests can restate the integer recurrence.  fast_S / fast_H / int_g: 2604 entries,
+ * int_T: 239 * 64; consts = init_S, RC, salt, temp_k, g_cut, f64 tables usable, int tables usable,
+ * entry count. */
+int msspe_host_pair_tables(const char *params_path, const msspe_chem *chem, float dg_threshold,
+                           double *fast_S, int32_t *fast_H, int32_t *int_g, int32_t *int_T,
+                           double consts[8]);
+
 /* Full thal record for explicit pairs (a_i, b_i), i < n -- what `ntthal` prints per input line
  * (od-msspe/src/delta_g.rs:206-230): dS (salt-corrected), dH, dG, t and the base pairs of the
  * traced structure.  mode 1 = ANY, 2 = END1.  Used by the ntthal protocol shim. */

@@ -35,6 +35,8 @@ struct ChemEntry {
     PairTables *d_pt = nullptr;   // 2 entries: ordinary, both self-complementary
     FastTables *d_ft = nullptr;   // tables of the tuned all-pairs kernel (ordinary pairs)
     bool fast_ok = false;
+    IntTables *d_it = nullptr;    // integer image for the exact-integer kernel
+    bool int_ok = false;
 };
 
 constexpr long kChunkPairs = 1L << 24;       // pairs per launch of the all-pairs kernel
@@ -56,6 +58,7 @@ struct msspe_ctx {
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
     uint32_t *ovf_count = nullptr;     // [0] first-stage counter, [1] second-stage counter
     uint64_t *d_ovf_total = nullptr;
+    unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
     uint32_t *d_perm = nullptr, *d_bins = nullptr;
     size_t sort_cap = 0;
@@ -132,6 +135,10 @@ int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntr
         e.fast_ok = build_fast_tables(ctx->host_tb, host_pt[0], pairs_fast_max_k(), *ft);
         HIP_TRY(ctx, hipMalloc((void **)&e.d_ft, sizeof(FastTables)));
         HIP_TRY(ctx, hipMemcpy(e.d_ft, ft.get(), sizeof(FastTables), hipMemcpyHostToDevice));
+        auto it = std::make_unique<IntTables>();
+        e.int_ok = e.fast_ok && build_int_tables(*ft, pairs_fast_max_k(), *it);
+        HIP_TRY(ctx, hipMalloc((void **)&e.d_it, sizeof(IntTables)));
+        HIP_TRY(ctx, hipMemcpy(e.d_it, it.get(), sizeof(IntTables), hipMemcpyHostToDevice));
     }
     ctx->chem_cache.push_back(e);
     *out = &ctx->chem_cache.back();
@@ -161,6 +168,8 @@ int ensure_overflow(msspe_ctx *ctx)
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (8 + 1024) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (8 + 1024) * sizeof(unsigned long long)));
     return MSSPE_OK;
 }
 
@@ -189,6 +198,14 @@ bool use_generic_only()
 {
     const char *e = std::getenv("MSSPE_FORCE_GENERIC");
     return e && *e && *e != '0';
+}
+
+// MSSPE_PAIR_KERNEL=f64 keeps the f64 register-table kernel as the first stage (testing aid);
+// the default first stage is the exact-integer kernel, with the f64 kernels behind it.
+bool use_f64_pairs()
+{
+    const char *e = std::getenv("MSSPE_PAIR_KERNEL");
+    return e && std::strcmp(e, "f64") == 0;
 }
 
 }  // namespace
@@ -260,6 +277,7 @@ void msspe_destroy(msspe_ctx *ctx)
         {
             if (e.d_pt) (void)hipFree(e.d_pt);
             if (e.d_ft) (void)hipFree(e.d_ft);
+            if (e.d_it) (void)hipFree(e.d_it);
         }
         if (ctx->wsS) (void)hipFree(ctx->wsS);
         if (ctx->wsH) (void)hipFree(ctx->wsH);
@@ -267,6 +285,7 @@ void msspe_destroy(msspe_ctx *ctx)
         if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
         if (ctx->ovf_count) (void)hipFree(ctx->ovf_count);
         if (ctx->d_ovf_total) (void)hipFree(ctx->d_ovf_total);
+        if (ctx->d_reasons) (void)hipFree(ctx->d_reasons);
         if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
         if (ctx->d_perm) (void)hipFree(ctx->d_perm);
         if (ctx->d_bins) (void)hipFree(ctx->d_bins);
@@ -397,6 +416,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         }
         return MSSPE_OK;
     }
+    const bool int_stage = ce->int_ok && !use_f64_pairs();
     if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
     HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
                                              ctx->d_perm, ctx->stream));
@@ -470,7 +490,8 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
-            HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
+            if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->stream));
+            else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
             if (ctx->prof_on)
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
             pending += launch_pairs;
@@ -514,6 +535,33 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(count_out, ctx->d_ovf_total, sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
+    return MSSPE_OK;
+}
+
+int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return MSSPE_ERR_ARG;
+    for (int q = 0; q < 8; ++q) out[q] = 0;
+    if (!ctx->d_reasons) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, 8 * sizeof(uint64_t)));
+    return MSSPE_OK;
+}
+
+int msspe_pair_stage_samples(msspe_ctx *ctx, uint64_t *out, int capacity, int *n_out)
+{
+    if (!ctx || !out || !n_out || capacity < 0) return MSSPE_ERR_ARG;
+    *n_out = 0;
+    if (!ctx->d_reasons) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t n = 0;
+    HIP_TRY(ctx, hipMemcpy(&n, ctx->d_reasons + 7, sizeof n, hipMemcpyDeviceToHost));
+    const int m = (int)std::min<uint64_t>(std::min<uint64_t>(n, 1024), (uint64_t)capacity);
+    if (m) HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons + 8, sizeof(uint64_t) * m, hipMemcpyDeviceToHost));
+    *n_out = m;
     return MSSPE_OK;
 }
 
@@ -758,6 +806,39 @@ int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t
                              : hip_fail(ctx, e, "hipMemcpy");
     (void)hipFree(d);
     return rc;
+}
+
+int msspe_host_pair_tables(const char *params_path, const msspe_chem *chem, float dg_threshold,
+                           double *fast_S, int32_t *fast_H, int32_t *int_g, int32_t *int_T,
+                           double consts[8])
+{
+    // host only (no device needed): what the all-pairs kernels keep in LDS, for the CPU tests
+    if (!chem || !fast_S || !fast_H || !int_g || !int_T || !consts) return MSSPE_ERR_ARG;
+    auto tb = std::make_unique<NNTables>();
+    std::string err;
+    const std::string path = params_path && *params_path ? params_path : default_bundle_path();
+    if (!load_nn_tables(path, *tb, err)) return MSSPE_ERR_TABLES;
+    const ThalConsts c = make_dimer_consts(chem->mv, chem->dv, chem->dntp, chem->dna_conc, chem->temp_c,
+                                           chem->max_loop, false, dg_threshold);
+    auto pt = std::make_unique<PairTables>();
+    if (!build_pair_tables(*tb, c, *pt, err)) return MSSPE_ERR_TABLES;
+    auto ft = std::make_unique<FastTables>();
+    auto it = std::make_unique<IntTables>();
+    const bool fast_ok = build_fast_tables(*tb, *pt, pairs_fast_max_k(), *ft);
+    const bool int_ok = fast_ok && build_int_tables(*ft, pairs_fast_max_k(), *it);
+    std::memcpy(fast_S, ft->S, sizeof ft->S);
+    std::memcpy(fast_H, ft->H, sizeof ft->H);
+    std::memcpy(int_g, it->g, sizeof it->g);
+    std::memcpy(int_T, it->T, sizeof it->T);
+    consts[0] = c.init_S;
+    consts[1] = c.RC;
+    consts[2] = c.salt;
+    consts[3] = c.temp_k;
+    consts[4] = c.g_cut;
+    consts[5] = fast_ok ? 1.0 : 0.0;
+    consts[6] = int_ok ? 1.0 : 0.0;
+    consts[7] = (double)FastTables::kCount;
+    return MSSPE_OK;
 }
 
 float msspe_round_g_f32(double x) { return round_g_f32(x); }

@@ -50,4 +50,37 @@ struct FastTables {
 //   * 2 * max_k - 4 <= kMaxSz (every loop an oligo pair can form has a table row).
 bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastTables &out);
 
+// Integer image of the same tables for the exact-integer kernel (thal_pairs_int.hip).
+// Every table entropy is a multiple of 0.01 e.u. and every enthalpy a multiple of 10 cal/mol, and
+// the interior-loop asymmetry term is ILAS * |l1 - l2| with 310.15 * ILAS = -300 exactly, so the
+// value of a DP cell is the integer triple (h = H / 10, s = 100 * S_tables, n = sum |l1 - l2|) and
+//      2000 * dG(37 C) = 20000 h + 600000 n - 6203 s         (dG = H - 310.15 S)
+// is an exact int32.  Primer3 compares dG values as doubles; two candidates whose exact values
+// differ are at least 5e-4 cal/mol apart, far beyond double rounding, so integer comparison
+// gives the same answer.  Exact ties (where double rounding decides) are detected and those
+// pairs are handed to the f64 kernel.
+struct IntTables {
+    static constexpr int kMaxL = 14;                       // l1, l2 <= k - 2
+    static constexpr int kRows = kMaxL * 17 + 1;           // row d = l1 * 16 + l2
+    // "not available" is a large value, not a flag.  A candidate is the sum of a loop entry, a
+    // cell-side entry and the predecessor's value: two unavailable terms must not wrap
+    // (2 kBig + kReach < 2^31) and a single one must land above kValid (kBig - kReach >= kValid),
+    // where kReach bounds every reachable |value| (checked by build_int_tables).
+    static constexpr int32_t kBig = 900000000;             // not available
+    static constexpr int32_t kValid = 500000000;           // candidates at or above this are void
+    static constexpr int32_t kReach = 300000000;
+    static constexpr int32_t kGh = 20000, kGn = 600000, kGs = 6203;
+    // loop term of predecessor p -> cell c without the cell-side mismatch term:
+    //   interior / 1x1 : column po (fast_tables.hpp), asymmetry included
+    //   bulge          : column a_p | a_c << 2
+    //   d = 0 (stack)  : kBig, the stacked pair is not a loop candidate
+    int32_t T[kRows * 64];
+    int32_t g[FastTables::kCount];   // kGh * (H / 10) - kGs * s per FastTables entry (kBig: unavailable)
+    int32_t s[FastTables::kCount];   // round(100 * S)
+    int32_t usable, max_k;
+};
+// usable = 0 unless every finite entropy is a multiple of 0.01 within 1e-7 and the packed fields
+// (s: 18 bits signed, sums below kValid) cannot overflow for oligos up to max_k bases.
+bool build_int_tables(const FastTables &ft, int max_k, IntTables &out);
+
 }  // namespace msspe

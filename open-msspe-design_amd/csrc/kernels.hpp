@@ -81,6 +81,12 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
 // that still do not fit are appended to a.overflow_list.
 hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
                              const uint32_t *in_count, hipStream_t stream);
+// Exact-integer first stage (thal_pairs_int.hip): same contract as launch_pairs_fast; pairs it does
+// not answer (ties, oversized tables) are appended to a.overflow_list.  reasons: optional device
+// counters [8] ([0] = pairs handed on because of a tie, [1 + b] = reason bit b, see the kernel).
+hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
+                            hipStream_t stream);
+int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();
 hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k,

@@ -8,6 +8,7 @@
 #include "nn_params.hpp"
 #include "fast_tables.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -505,6 +506,79 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
     // terms, each >= min_S; plus two end terms
     if (3.0 * min_S * (max_k + 2) < -2500.0) ok = false;
     if (2 * max_k - 4 > FastTables::kMaxSz) ok = false;
+    out.usable = ok ? 1 : 0;
+    out.max_k = max_k;
+    return ok;
+}
+
+bool build_int_tables(const FastTables &ft, int max_k, IntTables &out)
+{
+    std::memset(&out, 0, sizeof out);
+    bool ok = ft.usable != 0 && max_k <= IntTables::kMaxL + 2;
+    long max_abs_g = 0, max_abs_s = 0;
+    for (int e = 0; e < FastTables::kCount; ++e) {
+        const bool zt = e >= FastTables::kZT && e < FastTables::kZT + 64;   // asymmetry: carried as n
+        if (ft.H[e] >= kHInf) {
+            out.g[e] = IntTables::kBig;
+            out.s[e] = 0;
+            continue;
+        }
+        if (zt) {
+            const int d = e - (FastTables::kZT + 32);
+            out.g[e] = IntTables::kGn * (d < 0 ? -d : d);
+            out.s[e] = 0;
+            continue;
+        }
+        const double s100 = ft.S[e] * 100.0;
+        const double r = std::nearbyint(s100);
+        if (std::fabs(s100 - r) > 1e-7 || std::fabs(r) > 1e5 || ft.H[e] % 10 != 0) ok = false;
+        const long si = (long)r, hi = ft.H[e] / 10;
+        const long g = (long)IntTables::kGh * hi - (long)IntTables::kGs * si;
+        if (std::labs(g) > max_abs_g) max_abs_g = std::labs(g);
+        if (std::labs(si) > max_abs_s) max_abs_s = std::labs(si);
+        out.g[e] = (int32_t)g;
+        out.s[e] = (int32_t)si;
+    }
+    // Range of a reachable value: a path spends the 2 * max_k bases of the two oligos, a stacked
+    // pair costs 2 of them and a loop of size sz costs sz + 2, so |G| <= 2 * max_k * (largest
+    // |g| per base) + two end terms.  It must stay below kReach (fast_tables.hpp).
+    {
+        (void)max_abs_g;
+        (void)max_abs_s;
+        auto mag = [&](int e) -> double {
+            return out.g[e] == IntTables::kBig ? 0.0 : std::fabs((double)out.g[e]);
+        };
+        double per_base = 0.0, mm = 0.0, en = 0.0;
+        for (int e = FastTables::kWC; e < FastTables::kWC + 16; ++e) per_base = std::max(per_base, mag(e) / 2.0);
+        for (int e = FastTables::kTSc; e < FastTables::kZero; ++e) mm = std::max(mm, mag(e));
+        for (int sz = 2; sz <= FastTables::kMaxSz; ++sz)
+            for (int po = 0; po < 64; ++po)
+                per_base = std::max(per_base, (mag(FastTables::kNB + (sz - 2) * 64 + po) + mm +
+                                               (double)IntTables::kGn * sz) / (sz + 2));
+        for (int ac = 0; ac < 4; ++ac)
+            for (int sz = 1; sz <= FastTables::kMaxSz; ++sz)
+                for (int ap = 0; ap < 4; ++ap)
+                    per_base = std::max(per_base,
+                                        mag(FastTables::kBU + ac * FastTables::kBUStride + sz * 4 + ap) / (sz + 2));
+        for (int e = FastTables::kEndL; e < FastTables::kWC; ++e) en = std::max(en, mag(e));
+        if (2.0 * max_k * per_base + 2.0 * en + mm >= IntTables::kReach) ok = false;
+    }
+    for (int d = 0; d < IntTables::kRows; ++d)
+        for (int pe = 0; pe < 64; ++pe) {
+            const int l1 = d >> 4, l2 = d & 15, sz = l1 + l2;
+            int32_t v = IntTables::kBig;
+            if (d != 0 && l1 <= IntTables::kMaxL && l2 <= IntTables::kMaxL && sz <= FastTables::kMaxSz) {
+                if (l1 == 0 || l2 == 0) {
+                    if (pe < 16)
+                        v = out.g[FastTables::kBU + (pe >> 2) * FastTables::kBUStride + sz * 4 + (pe & 3)];
+                } else {
+                    v = out.g[FastTables::kNB + (sz - 2) * 64 + pe];
+                    if (v != IntTables::kBig && d != 0x11)
+                        v += IntTables::kGn * (l1 > l2 ? l1 - l2 : l2 - l1);
+                }
+            }
+            out.T[d * 64 + pe] = v;
+        }
     out.usable = ok ? 1 : 0;
     out.max_k = max_k;
     return ok;

@@ -1,0 +1,521 @@
+// thal_pairs_int.hip -- all-pairs cross-dimer kernel, exact-integer DP (thal ANY per ordered pair).
+//
+// Same job and same outputs as thal_pairs.hip (the reference's "format N^2 lines -> ntthal ->
+// parse" loop, /root/reference/od-msspe/src/delta_g.rs:61-153; Primer3 2.6.1 thal() restated from
+// SURVEY.md Appendix C.3), but the O(cells^2) part -- every earlier cell tried as the predecessor
+// of every cell -- runs on int32 instead of f64:
+//   * a cell's value is the exact triple (h, s, n) of fast_tables.hpp (IntTables); its dG at
+//     37 C is the int32 G = 20000 h + 600000 n - 6203 s, and (G, h) is all a slot keeps: the
+//     total entropy is (20000 h - G) / 620300.  fillMatrix's acceptance test
+//     "dG(candidate) < dG(current)" is decided on G: one LDS gather T[d][po] + one add3 + one
+//     compare per predecessor, where d = 16 l1 + l2 falls out of a single subtraction of packed
+//     coordinates.  Exact values that differ are >= 5e-4 cal/mol apart, so the double comparison
+//     Primer3 makes gives the same answer; only exact ties can go either way in doubles.
+//   * maxTM's "extend the helix if Tm rises" compares two quotients; it is evaluated in f64 from
+//     the integer state (cross-multiplied, no division) and is decisive unless the two sides
+//     agree to 1e-9.
+//   * a pair that meets an exact tie, a near-tie of Tm, a rejected (H > 0, S > 0) winner or more
+//     cells than the table holds is NOT answered here: it goes to the overflow list and is
+//     finished by the f64 kernels.  Nothing is approximated.
+//   * each cell records its predecessor; the optimal path is walked by pointer, written to an LDS
+//     scratch [step][thread] and then REPLAYED forwards in f64 with Primer3's own operation order
+//     (pair_core.hpp cand_* = the f64 kernel's formulas), so dS, dH, dG and t carry the same bits
+//     as the CPU oracle.
+// CDNA4 mapping: lane = ordered pair, wave = one row x 64 composition-sorted columns, 512-thread
+// persistent blocks (one per CU, two waves per SIMD, up to 256 VGPRs): 56 slots x {G, W} live in
+// registers behind a switch over the wave-uniform chunk number; LDS holds the 61 KB loop table,
+// the compact f64 / int tables, the predecessor bytes [slot][thread] and the path scratch.
+#include "pair_core.hpp"
+
+namespace msspe {
+
+namespace {
+
+constexpr int kC = 4;              // slots per chunk (= predecessor evaluations in flight)
+constexpr int kNCh = 14;           // chunks: 56 slots, all in VGPRs
+constexpr int kSlotsI = kC * kNCh;
+constexpr int kThreadsI = 512;
+constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
+constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
+
+// slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 14 | po << 8 | im1 << 4 | jm1
+// (the f64 kernel's word).  The predecessor of the cell (im1 << 4 | jm1, 0xff: none) is only
+// read by the traceback and lives in LDS.
+struct ISlots {
+    int G[kSlotsI];
+    int W[kSlotsI];
+};
+
+struct SharedI {
+    int T[IntTables::kRows * 64];
+    Lds F;                              // f64 S + int H (replay, end terms)
+    int g[FastTables::kCount];
+    unsigned char pred[kSlotsI][kThreadsI];
+    unsigned short path[kPathMax][kThreadsI];
+};
+
+struct ICell {
+    int cgeo;      // (im1 - 1) * 16 + (jm1 - 1)
+    int jm1p;      // jm1 - 1
+    int a4;        // cell base << 2 (bulge column)
+    int yTS, yMM;  // cell-side mismatch term of interior / 1x1 loops (G units)
+};
+
+struct IBest {
+    int G, W;   // candidate value; predecessor's packed word
+};
+
+// Keeps the cases of the chunk switches apart: without it the optimiser folds "case k: x = a[8k+q]"
+// into one dynamically indexed load, which sends the whole table to scratch memory.
+__device__ __forceinline__ int pin(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void fetch2(const ISlots &st, int pc, int (&G)[kC], int (&W)[kC])
+{
+#define MSSPE_FETCH2(PC)                                                       \
+    case PC:                                                                   \
+        if constexpr (PC < kNCh) {                                             \
+            _Pragma("unroll") for (int q = 0; q < kC; ++q) {                   \
+                G[q] = pin(st.G[(PC < kNCh ? PC : 0) * kC + q]);               \
+                W[q] = pin(st.W[(PC < kNCh ? PC : 0) * kC + q]);               \
+            }                                                                  \
+        }                                                                      \
+        break;
+    switch (pc) {
+        MSSPE_FETCH2(0) MSSPE_FETCH2(1) MSSPE_FETCH2(2) MSSPE_FETCH2(3) MSSPE_FETCH2(4) MSSPE_FETCH2(5)
+        MSSPE_FETCH2(6) MSSPE_FETCH2(7) MSSPE_FETCH2(8) MSSPE_FETCH2(9) MSSPE_FETCH2(10) MSSPE_FETCH2(11)
+        MSSPE_FETCH2(12) MSSPE_FETCH2(13) MSSPE_FETCH2(14) MSSPE_FETCH2(15)
+    default: break;
+    }
+#undef MSSPE_FETCH2
+}
+
+__device__ __forceinline__ void fetch1(const ISlots &st, int pc, int (&W)[kC])
+{
+#define MSSPE_FETCH1(PC)                                                       \
+    case PC:                                                                   \
+        if constexpr (PC < kNCh) {                                             \
+            _Pragma("unroll") for (int q = 0; q < kC; ++q)                     \
+                W[q] = pin(st.W[(PC < kNCh ? PC : 0) * kC + q]);               \
+        }                                                                      \
+        break;
+    switch (pc) {
+        MSSPE_FETCH1(0) MSSPE_FETCH1(1) MSSPE_FETCH1(2) MSSPE_FETCH1(3) MSSPE_FETCH1(4) MSSPE_FETCH1(5)
+        MSSPE_FETCH1(6) MSSPE_FETCH1(7) MSSPE_FETCH1(8) MSSPE_FETCH1(9) MSSPE_FETCH1(10) MSSPE_FETCH1(11)
+        MSSPE_FETCH1(12) MSSPE_FETCH1(13) MSSPE_FETCH1(14) MSSPE_FETCH1(15)
+    default: break;
+    }
+#undef MSSPE_FETCH1
+}
+
+template <int PC = 0>
+__device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
+{
+    if constexpr (PC < kNCh) {
+        if (slot < (PC + 1) * kC) {
+            // the trailing asm differs per case, so the stores cannot be sunk into one indexed store
+#define MSSPE_ST(Q)                       \
+    st.G[PC * kC + Q] = G;                \
+    st.W[PC * kC + Q] = W;                \
+    asm volatile("" ::"n"(PC * kC + Q));  \
+    break;
+            switch (slot - PC * kC) {
+            case 0: MSSPE_ST(0)
+            case 1: MSSPE_ST(1)
+            case 2: MSSPE_ST(2)
+            default: MSSPE_ST(3)
+            }
+#undef MSSPE_ST
+        } else {
+            store2<PC + 1>(st, slot, G, W);
+        }
+    }
+}
+
+// One predecessor slot against cell c.  `tie` collects exact ties with the running minimum.
+struct Visit {
+    int idx;     // T index (clamped)
+    int y;       // cell-side term for this kind of loop
+    bool geo;    // predecessor lies strictly up-left of the cell, or is the cell (i-1, j-1)
+    bool stack;  // ... the latter
+};
+
+__device__ __forceinline__ Visit visit_geometry(const ICell &c, int Wp)
+{
+    Visit v;
+    const int d = c.cgeo - (Wp & 0xff);
+    const int jj = Wp & 15;
+    v.geo = (jj <= c.jm1p) & (d >= 0);
+    v.stack = v.geo & (d == 0);
+    const int po = (Wp >> 8) & 63;
+    const bool bulge = (d < 16) | ((d & 15) == 0);
+    const int pe = bulge ? ((po & 3) | c.a4) : po;
+    v.idx = (int)min((unsigned)(d * 64 + pe), (unsigned)(IntTables::kRows * 64 - 1));
+    v.y = d == 0x11 ? c.yMM : (bulge ? 0 : c.yTS);
+    return v;
+}
+
+__device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int Wp, IBest &best,
+                                             bool &tie, IBest &stk, bool &stHave)
+{
+    const int cand = t + v.y + Gp;   // unavailable rows hold kBig: never below best.G <= kValid
+    const bool better = v.geo & (cand < best.G);
+    const bool eq = v.geo & (cand == best.G);
+    tie = better ? false : (tie | eq);
+    best.G = better ? cand : best.G;
+    best.W = better ? Wp : best.W;
+    stk.G = v.stack ? Gp : stk.G;
+    stk.W = v.stack ? Wp : stk.W;
+    stHave = stHave | v.stack;
+}
+
+__device__ __forceinline__ void scan_fill_int(const ISlots &st, int upto, const int *T, const ICell &c,
+                                              IBest &best, bool &tie, IBest &stk, bool &stHave)
+{
+    const int nch = (upto + kC - 1) / kC;   // wave-uniform
+    for (int pc_ = 0; pc_ < nch; ++pc_) {
+        const int pc = __builtin_amdgcn_readfirstlane(pc_);
+        int G[kC], W[kC];
+        fetch2(st, pc, G, W);
+        Visit v[kC];
+        int t[kC];
+#pragma unroll
+        for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, W[e]);
+#pragma unroll
+        for (int e = 0; e < kC; ++e) t[e] = T[v[e].idx];
+#pragma unroll
+        for (int e = 0; e < kC; ++e) visit_finish(v[e], t[e], G[e], W[e], best, tie, stk, stHave);
+    }
+}
+
+// why a pair is not answered here (bit mask; statistics in IntArgs::reasons)
+enum : int {
+    kDeferTm = 1,        // maxTM: the two quotients agree to 1e-9
+    kDeferLoopEq = 2,    // best loop candidate ties with the cell's stack / start value
+    kDeferLoopTie = 4,   // two loop candidates tie for the minimum
+    kDeferBad = 8,       // the minimum has H > 0 and S > 0 (thal.c would reject it)
+    kDeferPick = 16,     // two cells tie in the terminal pick
+    kDeferReplay = 32,   // replayed enthalpy differs from the tracked one (never expected)
+};
+
+struct IntResult {
+    PairResult r;
+    int defer;   // not answered here: OR of the reasons above
+};
+
+// total entropy of a value from its exact (G, H): dG = H - 310.15 S and G = 2000 dG
+__device__ __forceinline__ double entropy_of(int G, int H)
+{
+    return ((double)H * 2000.0 - (double)G) * (1.0 / 620300.0);
+}
+
+// thal ANY for the lane's pair.  n_cells == 0: idle lane.
+__device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
+                                                  unsigned rowmask, int n_cells, int nmax, ISlots &st)
+{
+    const Lds &F = sh.F;
+#pragma unroll
+    for (int x = 0; x < kSlotsI; ++x) {
+        st.G[x] = 0;
+        st.W[x] = kEmptyW;
+    }
+    int defer = 0;
+    CellCtx c;
+    c.rS = 0.0;
+    c.rH = 0;
+    c.im1p = c.jm1p = 0;
+    c.yTS = c.yMM = c.bBase = 0;
+    unsigned Rrem = rowmask, mrem = 0;
+    int im1 = 0, jm1 = 0;
+
+    for (int slot_ = 0; slot_ < nmax; ++slot_) {
+        const int slot = __builtin_amdgcn_readfirstlane(slot_);
+        // ---- next complementary cell in row-major order (as in thal_pairs.hip)
+        const bool newrow = mrem == 0;
+        const int t = __ffs((int)Rrem) - 1;
+        const int a_new = (q.s1 >> (t & 31)) & 3;
+        const unsigned m_new = spaced_mask(q.s2, 3 - a_new, q.lenmask);
+        im1 = newrow ? (t >> 1) : im1;
+        Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
+        mrem = newrow ? m_new : mrem;
+        jm1 = (__ffs((int)mrem) - 1) >> 1;
+        mrem &= mrem - 1;
+        im1 &= 15;
+        jm1 &= 15;
+        const CellBases b = cell_bases(q, im1, jm1, c);
+        ICell ic;
+        ic.cgeo = (im1 - 1) * 16 + (jm1 - 1);
+        ic.jm1p = jm1 - 1;
+        ic.a4 = b.a << 2;
+        ic.yTS = sh.g[c.yTS];
+        ic.yMM = sh.g[c.yMM];
+        // ---- all earlier slots as predecessors
+        IBest best, stk;
+        best.G = IntTables::kValid;
+        best.W = 0;
+        stk.G = stk.W = 0;
+        bool tie = false, stHave = false;
+        scan_fill_int(st, slot, sh.T, ic, best, tie, stk, stHave);
+        // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
+        //      sides, so T1 > T0  <=>  A1 * B0 > A0 * B1.
+        int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
+        if (stHave) {
+            const double rS = F.S[b.idxR];
+            const int rH = F.H[b.idxR];
+            const int H1 = (stk.W >> 14) * 10 + F.H[b.wc];
+            const int G1 = stk.G + sh.g[b.wc];
+            const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
+            const double B0 = ((entropy_of(G0, H0) + K.init_S) + rS) + K.RC;
+            const double B1 = ((entropy_of(G1, H1) + K.init_S) + rS) + K.RC;
+            const double lhs = A1 * B0, rhs = A0 * B1;
+            const bool sure = (B0 < 0.0) & (B1 < 0.0) &
+                              (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
+            flags |= sure ? 0 : kDeferTm;
+            if (lhs > rhs) {
+                H0 = H1;
+                G0 = G1;
+                pred = stk.W & 0xff;
+            }
+        }
+        // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
+        flags |= (best.G == G0 ? kDeferLoopEq : 0) | (((best.G < G0) & tie) ? kDeferLoopTie : 0);
+        if (best.G < G0) {
+            // exact enthalpy of the winning candidate from the compact tables
+            const CandGeom g = cand_geometry(c, best.W);
+            const int Hw = F.H[g.lx] + F.H[g.y] + (best.W >> 14) * 10;
+            // thal.c rejects a candidate with H > 0 and S > 0: never the case for a sensible
+            // minimum; if it is, leave the pair to the f64 kernel
+            flags |= ((Hw > 0) & (entropy_of(best.G, Hw) > -1e-6)) ? kDeferBad : 0;
+            H0 = Hw;
+            G0 = best.G;
+            pred = best.W & 0xff;
+        }
+        defer |= slot < n_cells ? flags : 0;   // lanes past their last cell compute garbage
+        // ---- publish the cell (idle lanes write a slot nobody reads)
+        store2(st, slot, G0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
+        sh.pred[slot][threadIdx.x] = (unsigned char)pred;
+    }
+
+    IntResult out;
+    out.r.none = n_cells == 0;
+    out.r.dG = INFINITY;
+    out.r.t = 0.0;
+    out.r.conflict = false;
+
+    // ---- terminal pick (thal.c thal(): strict minimum of dG incl. the right end term, first in
+    //      row-major order).  The 1e-6 nudges are the same on every cell and drop out.
+    int pickG = 0x7fffffff, pickW = 0;
+    bool pickTie = false;
+    const int nch = (nmax + kC - 1) / kC;
+    for (int pc_ = 0; pc_ < nch; ++pc_) {
+        const int pc = __builtin_amdgcn_readfirstlane(pc_);
+        int G[kC], W[kC];
+        fetch2(st, pc, G, W);
+#pragma unroll
+        for (int e = 0; e < kC; ++e) {
+            const int slot = pc * kC + e;
+            CellCtx dummy;
+            const CellBases b = cell_bases(q, (W[e] >> 4) & 15, W[e] & 15, dummy);
+            const int Gt = G[e] + sh.g[b.idxR];
+            const bool in = slot < n_cells;
+            const bool pick = in & (Gt < pickG);
+            pickTie = pick ? false : (pickTie | (in & (Gt == pickG)));
+            pickG = pick ? Gt : pickG;
+            pickW = pick ? W[e] : pickW;
+        }
+    }
+    defer |= pickTie ? kDeferPick : 0;
+
+    // ---- traceback by pointer: path cells (end first) into the LDS scratch
+    int P = 0;
+    {
+        int cur = pickW & 0xff;
+        bool done = out.r.none;
+        for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
+            const int pc = __builtin_amdgcn_readfirstlane(pc_);
+            int W[kC];
+            fetch1(st, pc, W);
+#pragma unroll
+            for (int e = kC - 1; e >= 0; --e) {
+                const int slot = pc * kC + e;
+                const int pr = sh.pred[slot][threadIdx.x];
+                const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
+                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(W[e] & 0x3fff);
+                P += hit ? 1 : 0;
+                cur = hit ? pr : cur;
+                done = done | (hit & (pr == 0xff));
+            }
+        }
+    }
+    // ---- replay the path forwards in f64, Primer3's operation order (fillMatrix / maxTM)
+    double S = 0.0;
+    int H = 0, prevW = 0;
+    {
+        const int maxP = wave_max(P);
+        for (int step_ = 0; step_ < maxP; ++step_) {
+            const int step = __builtin_amdgcn_readfirstlane(step_);
+            const int e = P - 1 - step;
+            if (e >= 0) {
+                const int Wc = sh.path[e & (kPathMax - 1)][threadIdx.x];
+                CellCtx cc;
+                const CellBases b = cell_bases(q, (Wc >> 4) & 15, Wc & 15, cc);
+                if (step == 0) {
+                    S = F.S[b.idxL];
+                    H = F.H[b.idxL];
+                } else if (((Wc & 0xff) - (prevW & 0xff)) == 0x11) {
+                    S = S + F.S[b.wc];
+                    H = H + F.H[b.wc];
+                } else {
+                    const CandGeom g = cand_geometry(cc, prevW);
+                    const CandLoad v = cand_gather(F, g);
+                    S = ((v.sLX + v.sY) + v.sZ) + S;
+                    H = v.hLX + v.hY + H;
+                }
+                prevW = Wc;
+            }
+        }
+    }
+    // the replayed enthalpy must be the tracked one; anything else is handed on
+    defer |= (!out.r.none & (H != (pickW >> 14) * 10)) ? kDeferReplay : 0;
+    // ---- thal.c drawDimer(): totals
+    {
+        CellCtx cc;
+        const CellBases b = cell_bases(q, (pickW >> 4) & 15, pickW & 15, cc);
+        const double rS = F.S[b.idxR];
+        const int rH = F.H[b.idxR];
+        const double dH = (double)(H + rH + 200);
+        const double dS = (S + rS) + K.init_S;
+        const int N = P - 1;
+        const double t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
+        const double G = dH - (K.temp_k * (dS + (N * K.salt)));
+        if (!out.r.none) {
+            out.r.dG = G;
+            out.r.t = t;
+            out.r.conflict = G <= K.g_cut;
+        }
+    }
+    out.defer = out.r.none ? 0 : defer;
+    return out;
+}
+
+struct IntArgs {
+    FastArgs f;
+    const IntTables *it;
+    unsigned long long *reasons;   // optional statistics [8]: [0] pairs handed on, [1 + b] reason bit b
+};
+
+__global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
+{
+    __shared__ SharedI sh;
+    for (int e = threadIdx.x; e < IntTables::kRows * 64; e += kThreadsI) sh.T[e] = a.it->T[e];
+    for (int e = threadIdx.x; e < FastTables::kCount; e += kThreadsI) {
+        sh.F.S[e] = a.f.ft->S[e];
+        sh.F.H[e] = a.f.ft->H[e];
+        sh.g[e] = a.it->g[e];
+    }
+    __syncthreads();
+    ISlots st;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kRowsPerBlock = kThreadsI / 64;
+    const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
+    const int nrowg = (a.f.row1 - a.f.row0 + kRowsPerBlock - 1) / kRowsPerBlock;
+    const long tiles = (long)ncolg * nrowg;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int rg = (int)(tile / ncolg), cg = (int)(tile % ncolg);
+        const int row = a.f.row0 + rg * kRowsPerBlock + wave;
+        const int cq = a.f.col0 + cg * 64 + lane;
+        if (row >= a.f.row1) continue;   // wave-uniform
+        const bool inside = cq < a.f.col1;
+        const uint64_t pa = a.f.pool[row];
+        const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
+        const int col = (int)a.f.perm[inside ? cq : a.f.col0];
+        SeqPair q;
+        unsigned rowmask;
+        int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
+        const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
+        bool spill = inside & ((n_cells > kSlotsI) | sym);
+        if (!inside | spill) n_cells = 0;
+        const int nmax = wave_max(n_cells);
+        const IntResult r = run_pair_int(sh, a.f.c, q, rowmask, n_cells, nmax, st);
+        const bool deferred = inside & !spill & (r.defer != 0);
+        spill |= deferred;
+        if (spill) {
+            const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
+            if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
+        }
+        if (a.reasons) {
+            const unsigned long long dm = __ballot(deferred);
+            if (dm) {   // wave-uniform
+                if (lane == 0) atomicAdd(&a.reasons[0], (unsigned long long)__popcll(dm));
+#pragma unroll
+                for (int bit = 0; bit < 6; ++bit) {
+                    const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
+                    if (lane == 0 && bm) atomicAdd(&a.reasons[1 + bit], (unsigned long long)__popcll(bm));
+                }
+                // a few samples for diagnostics: row << 40 | col << 16 | reasons
+                if (deferred && a.reasons[7] < 1024ull) {
+                    const unsigned long long at = atomicAdd(&a.reasons[7], 1ull);
+                    if (at < 1024ull)
+                        a.reasons[8 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
+                                            (unsigned long long)r.defer;
+                }
+            }
+        }
+        // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
+        const bool live = inside & !spill;
+        const bool hit = live & r.r.conflict;
+        const unsigned long long bits = __ballot(hit);
+        const size_t orow = (size_t)(row - a.f.sinks.row0);
+        const size_t ocol = (size_t)(col - a.f.sinks.col0);
+        if (hit && a.f.sinks.bitmap)
+            atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
+                     1ull << (ocol & 63));
+        if (lane == 0 && a.f.sinks.row_conflicts && bits)
+            atomicAdd(&a.f.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+        if (live) {
+            if (a.f.sinks.dg) a.f.sinks.dg[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.dG;
+            if (a.f.sinks.tm) a.f.sinks.tm[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.t;
+        }
+    }
+}
+
+}  // namespace
+
+int pairs_int_slots() { return kSlotsI; }
+
+hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
+                            hipStream_t stream)
+{
+    IntArgs x;
+    FastArgs &f = x.f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.cols_sorted = a.cols_sorted;
+    f.perm = a.perm;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    x.it = it;
+    x.reasons = reasons;
+    constexpr int kRowsPerBlock = kThreadsI / 64;
+    const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
+                       (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
+    if (tiles <= 0) return hipSuccess;
+    const int grid = (int)(tiles < 256L * 4 ? tiles : 256L * 4);
+    hipLaunchKernelGGL(k_pairs_int, dim3(grid), dim3(kThreadsI), 0, stream, x);
+    return hipGetLastError();
+}
+
+}  // namespace msspe

@@ -16,7 +16,7 @@ EXPORTS = [
     "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
-    "msspe_last_overflow_pairs", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
+    "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
     "msspe_round_fixed_f32", "msspe_g_cut",
@@ -86,6 +86,8 @@ def load_library() -> C.CDLL:
     L.msspe_cross_dimer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
                                     vp, vp, vp, vp]
     L.msspe_last_overflow_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.msspe_pair_stage_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.msspe_pair_stage_samples.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
     L.msspe_profile_enable.argtypes = [vp, C.c_int]
     L.msspe_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     L.msspe_oligo_stats_dev.argtypes = [vp, u64p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
@@ -228,6 +230,21 @@ class Engine:
         v = C.c_uint64()
         self._check(self.L.msspe_last_overflow_pairs(self.ptr, C.byref(v)))
         return int(v.value)
+
+    def pair_stage_samples(self):
+        """[(row, col, reason bits)] for up to 1024 pairs the integer stage handed on."""
+        v = (C.c_uint64 * 1024)()
+        n = C.c_int(0)
+        self._check(self.L.msspe_pair_stage_samples(self.ptr, v, 1024, C.byref(n)))
+        return [(int(x >> 40), int((x >> 16) & 0xffffff), int(x & 0xffff)) for x in v[:n.value]]
+
+    def pair_stage_stats(self) -> dict:
+        """Diagnostics of the exact-integer first stage since the last call (resets them)."""
+        v = (C.c_uint64 * 8)()
+        self._check(self.L.msspe_pair_stage_stats(self.ptr, v))
+        names = ("deferred", "tm_near_tie", "loop_eq_value", "loop_tie", "rejected_min", "pick_tie",
+                 "replay_mismatch")
+        return {n: int(v[i]) for i, n in enumerate(names)}
 
     # ---- stage B ---------------------------------------------------------------------------
     def oligo_stats(self, pool, chem: Chem | None = None):

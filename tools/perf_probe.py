@@ -29,6 +29,7 @@ def main():
         run()
         torch.cuda.synchronize()
         ovf = eng.last_overflow_pairs()
+        stats = eng.pair_stage_stats()
         t0 = time.time()
         reps = 2
         for _ in range(reps):
@@ -37,6 +38,8 @@ def main():
         dt = (time.time() - t0) / reps
         print(f"n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
               f"overflow pairs={ovf} ({100.0*ovf/(n*n):.2f} %)", flush=True)
+        print("   integer stage:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats.items()}, flush=True)
+        eng.pair_stage_stats()
 
 
 if __name__ == "__main__":
