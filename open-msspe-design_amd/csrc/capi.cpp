@@ -56,7 +56,7 @@ struct msspe_ctx {
     size_t ws_cells = 0;
     uint2 *ovf_list = nullptr;         // pairs the main kernel could not hold
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
-    uint32_t *ovf_count = nullptr;     // [0] first-stage counter, [1] second-stage counter
+    uint32_t *ovf_count = nullptr;     // list counters of the stages: [0] first, [1] second, [2] third
     uint64_t *d_ovf_total = nullptr;
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
@@ -438,22 +438,38 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         a.col0 = 0;
         a.col1 = ncols;
         a.sinks = sinks;
-        // second stage: the wide table over the overflow list
-        a.overflow_list = ctx->ovf_list2;
-        a.overflow_count = ctx->ovf_count + 1;
+        // list A (ovf_list, counter 0) = what the first stage could not answer
+        const uint2 *in_list = ctx->ovf_list;
+        uint2 *out_list = ctx->ovf_list2;
+        int in_c = 0, out_c = 1;
+        if (int_stage) {
+            // the integer stage hands on ties as well as oversized tables: the 56-slot f64 table
+            // first, so that only the latter reach the wide kernel
+            a.overflow_list = out_list;
+            a.overflow_count = ctx->ovf_count + out_c;
+            a.overflow_cap = (uint32_t)kListCap;
+            HIP_TRY(ctx, launch_pairs_main_list(a, in_list, ctx->ovf_count + in_c, ctx->stream));
+            in_list = ctx->ovf_list2;
+            out_list = ctx->ovf_list;   // list A is consumed by now
+            in_c = 1;
+            out_c = 2;
+        }
+        // the wide table over the list
+        a.overflow_list = out_list;
+        a.overflow_count = ctx->ovf_count + out_c;
         a.overflow_cap = (uint32_t)kListCap;
-        HIP_TRY(ctx, launch_pairs_wide(a, ctx->ovf_list, ctx->ovf_count, ctx->stream));
-        // third stage: whatever is left (huge tables, both-self-complementary pairs)
-        g.list = ctx->ovf_list2;
-        g.list_count = ctx->ovf_count + 1;
+        HIP_TRY(ctx, launch_pairs_wide(a, in_list, ctx->ovf_count + in_c, ctx->stream));
+        // last stage: whatever is left (huge tables, both-self-complementary pairs)
+        g.list = out_list;
+        g.list_count = ctx->ovf_count + out_c;
         g.n_work = kListCap;
         HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
         hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
                            ctx->d_ovf_total);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
         return MSSPE_OK;
     };
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
     long pending = 0;   // worst-case entries the list may hold
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
         const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);

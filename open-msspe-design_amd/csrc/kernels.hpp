@@ -77,6 +77,10 @@ struct PairKernelArgs {
     uint32_t overflow_cap;
 };
 hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
+// The main table over an explicit pair list (what the integer stage handed on); pairs that do not
+// fit are appended to a.overflow_list.
+hipError_t launch_pairs_main_list(const PairKernelArgs &a, const uint2 *in_list,
+                                  const uint32_t *in_count, hipStream_t stream);
 // Wide instantiation over an explicit pair list (the overflow list of launch_pairs_fast); pairs
 // that still do not fit are appended to a.overflow_list.
 hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,

@@ -461,14 +461,14 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
     }
 }
 
-// List mode: lane = one explicit pair (the overflow list of the matrix kernel).  128-thread
+// List mode: lane = one explicit pair (the list a previous stage left behind).  THREADS-wide
 // blocks: 40 register slots + NEXT * 8 LDS slots per lane, two blocks per CU.
-template <int NREG, int NEXT>
-__global__ void __launch_bounds__(128, 1) k_pairs_list(FastArgs a)
+template <int NREG, int NEXT, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs a)
 {
     struct Shared {
         Lds T;
-        LdsExt<NEXT, 128> X;
+        LdsExt<NEXT, THREADS> X;
     };
     __shared__ Shared sh;
     Lds &T = sh.T;
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(128, 1) k_pairs_list(FastArgs a)
     Slots<NREG, NEXT> st;
     st.xS = &sh.X.S[0][threadIdx.x];
     st.xW = &sh.X.W[0][threadIdx.x];
-    st.xstride = 128;
+    st.xstride = THREADS;
     constexpr int NCH = NREG + NEXT;
     const long n_work = (long)min(*a.in_count, a.ovf_cap);
     const long stride = (long)gridDim.x * blockDim.x;
@@ -553,6 +553,39 @@ hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+namespace {
+FastArgs list_args(const PairKernelArgs &a, const uint2 *in_list, const uint32_t *in_count)
+{
+    FastArgs f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.cols_sorted = nullptr;
+    f.perm = nullptr;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = in_list;
+    f.in_count = in_count;
+    return f;
+}
+}  // namespace
+
+// The main table (56 slots) over an explicit pair list: finishes what the integer stage handed on.
+hipError_t launch_pairs_main_list(const PairKernelArgs &a, const uint2 *in_list,
+                                  const uint32_t *in_count, hipStream_t stream)
+{
+    const FastArgs f = list_args(a, in_list, in_count);
+    hipLaunchKernelGGL((k_pairs_list<kNregMain, kNextMain, 256>), dim3(256 * 2), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+
 hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
                              const uint32_t *in_count, hipStream_t stream)
 {
@@ -573,7 +606,7 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
     f.ovf_cap = a.overflow_cap;
     f.in_list = in_list;
     f.in_count = in_count;
-    hipLaunchKernelGGL((k_pairs_list<kNregWide, kNextWide>), dim3(256 * 4), dim3(128), 0, stream, f);
+    hipLaunchKernelGGL((k_pairs_list<kNregWide, kNextWide, 128>), dim3(256 * 4), dim3(128), 0, stream, f);
     return hipGetLastError();
 }
 

@@ -38,9 +38,9 @@ constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
 constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
 
-// slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 14 | po << 8 | im1 << 4 | jm1
-// (the f64 kernel's word).  The predecessor of the cell (im1 << 4 | jm1, 0xff: none) is only
-// read by the traceback and lives in LDS.
+// slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
+// (bits 8, 9 zero, so that bits 8..15 read as po * 4, a byte offset).  The predecessor of the
+// cell (im1 << 4 | jm1, 0xff: none) is only read by the traceback and lives in LDS.
 struct ISlots {
     int G[kSlotsI];
     int W[kSlotsI];
@@ -56,14 +56,21 @@ struct SharedI {
 
 struct ICell {
     int cgeo;      // (im1 - 1) * 16 + (jm1 - 1)
+    int cstk;      // packed coordinates of (i-1, j-1), or a value no slot holds (first row / column)
     int jm1p;      // jm1 - 1
-    int a4;        // cell base << 2 (bulge column)
+    int a16;       // cell base << 4 (bulge column, pre-multiplied by 4 like po)
     int yTS, yMM;  // cell-side mismatch term of interior / 1x1 loops (G units)
 };
 
 struct IBest {
     int G, W;   // candidate value; predecessor's packed word
 };
+
+// the f64 kernel's word (h << 14 | po << 8 | im1 << 4 | jm1) of pair_core.hpp's cand_* helpers
+__device__ __forceinline__ int core_word(int W)
+{
+    return ((W >> 16) << 14) | ((W >> 2) & 0x3f00) | (W & 0xff);
+}
 
 // Keeps the cases of the chunk switches apart: without it the optimiser folds "case k: x = a[8k+q]"
 // into one dynamically indexed load, which sends the whole table to scratch memory.
@@ -135,12 +142,18 @@ __device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
     }
 }
 
-// One predecessor slot against cell c.  `tie` collects exact ties with the running minimum.
+// One predecessor slot against cell c.
 struct Visit {
-    int idx;     // T index (clamped)
+    int idx4;    // byte offset into T (0 = the kBig row when the geometry is invalid)
     int y;       // cell-side term for this kind of loop
     bool geo;    // predecessor lies strictly up-left of the cell, or is the cell (i-1, j-1)
     bool stack;  // ... the latter
+};
+
+// wave-uniform lane masks carried through the scan (scalar registers, no VALU work)
+struct ScanMasks {
+    unsigned long long tie;      // lanes whose running minimum is shared by two candidates
+    unsigned long long stHave;   // lanes that met their (i-1, j-1) predecessor
 };
 
 __device__ __forceinline__ Visit visit_geometry(const ICell &c, int Wp)
@@ -149,45 +162,52 @@ __device__ __forceinline__ Visit visit_geometry(const ICell &c, int Wp)
     const int d = c.cgeo - (Wp & 0xff);
     const int jj = Wp & 15;
     v.geo = (jj <= c.jm1p) & (d >= 0);
-    v.stack = v.geo & (d == 0);
-    const int po = (Wp >> 8) & 63;
+    v.stack = (Wp & 0xff) == c.cstk;         // the cell (i-1, j-1)
+    const int po4 = (Wp >> 8) & 0xff;        // po << 2 (bits 8, 9 of W are zero)
     const bool bulge = (d < 16) | ((d & 15) == 0);
-    const int pe = bulge ? ((po & 3) | c.a4) : po;
-    v.idx = (int)min((unsigned)(d * 64 + pe), (unsigned)(IntTables::kRows * 64 - 1));
+    const int pe4 = bulge ? ((po4 & 12) | c.a16) : po4;
+    // a valid geometry has 0 <= d <= 238 and pe4 < 256: in range.  Everything else reads T[0], the
+    // stacked-pair row, which holds kBig: no clamp and no separate validity mask in the compares.
+    v.idx4 = v.geo ? ((d << 8) | pe4) : 0;
     v.y = d == 0x11 ? c.yMM : (bulge ? 0 : c.yTS);
     return v;
 }
 
 __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int Wp, IBest &best,
-                                             bool &tie, IBest &stk, bool &stHave)
+                                             IBest &stk, ScanMasks &m)
 {
-    const int cand = t + v.y + Gp;   // unavailable rows hold kBig: never below best.G <= kValid
-    const bool better = v.geo & (cand < best.G);
-    const bool eq = v.geo & (cand == best.G);
-    tie = better ? false : (tie | eq);
+    const int cand = t + v.y + Gp;   // unavailable / invalid: kBig + ..., never below best.G <= kValid
+    const bool better = cand < best.G;
+    const bool eq = cand == best.G;
+    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
     best.G = better ? cand : best.G;
     best.W = better ? Wp : best.W;
     stk.G = v.stack ? Gp : stk.G;
     stk.W = v.stack ? Wp : stk.W;
-    stHave = stHave | v.stack;
+    m.stHave |= __builtin_amdgcn_ballot_w64(v.stack);
 }
 
-__device__ __forceinline__ void scan_fill_int(const ISlots &st, int upto, const int *T, const ICell &c,
-                                              IBest &best, bool &tie, IBest &stk, bool &stHave)
+// All earlier slots as predecessors of cell c, kC at a time.  The chunks are unrolled with
+// compile-time register numbers and left through a wave-uniform branch at the first chunk that
+// holds no computed slot (later slots are empty and would fail the geometry test anyway).
+template <int PC = 0>
+__device__ __forceinline__ void scan_fill_int(const ISlots &st, int upto, const char *T, const ICell &c,
+                                              IBest &best, IBest &stk, ScanMasks &m)
 {
-    const int nch = (upto + kC - 1) / kC;   // wave-uniform
-    for (int pc_ = 0; pc_ < nch; ++pc_) {
-        const int pc = __builtin_amdgcn_readfirstlane(pc_);
-        int G[kC], W[kC];
-        fetch2(st, pc, G, W);
-        Visit v[kC];
-        int t[kC];
+    if constexpr (PC < kNCh) {
+        if (PC * kC < upto) {   // wave-uniform
+            asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
+            Visit v[kC];
+            int t[kC];
 #pragma unroll
-        for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, W[e]);
+            for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, st.W[PC * kC + e]);
 #pragma unroll
-        for (int e = 0; e < kC; ++e) t[e] = T[v[e].idx];
+            for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
 #pragma unroll
-        for (int e = 0; e < kC; ++e) visit_finish(v[e], t[e], G[e], W[e], best, tie, stk, stHave);
+            for (int e = 0; e < kC; ++e)
+                visit_finish(v[e], t[e], st.G[PC * kC + e], st.W[PC * kC + e], best, stk, m);
+            scan_fill_int<PC + 1>(st, upto, T, c, best, stk, m);
+        }
     }
 }
 
@@ -249,7 +269,8 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         ICell ic;
         ic.cgeo = (im1 - 1) * 16 + (jm1 - 1);
         ic.jm1p = jm1 - 1;
-        ic.a4 = b.a << 2;
+        ic.cstk = ((im1 > 0) & (jm1 > 0)) ? ic.cgeo : 0x100;
+        ic.a16 = b.a << 4;
         ic.yTS = sh.g[c.yTS];
         ic.yMM = sh.g[c.yMM];
         // ---- all earlier slots as predecessors
@@ -257,15 +278,18 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         best.G = IntTables::kValid;
         best.W = 0;
         stk.G = stk.W = 0;
-        bool tie = false, stHave = false;
-        scan_fill_int(st, slot, sh.T, ic, best, tie, stk, stHave);
+        ScanMasks sm;
+        sm.tie = sm.stHave = 0ull;
+        scan_fill_int(st, slot, (const char *)sh.T, ic, best, stk, sm);
+        const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
+        const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
         //      sides, so T1 > T0  <=>  A1 * B0 > A0 * B1.
         int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
         if (stHave) {
             const double rS = F.S[b.idxR];
             const int rH = F.H[b.idxR];
-            const int H1 = (stk.W >> 14) * 10 + F.H[b.wc];
+            const int H1 = (stk.W >> 16) * 10 + F.H[b.wc];
             const int G1 = stk.G + sh.g[b.wc];
             const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
             const double B0 = ((entropy_of(G0, H0) + K.init_S) + rS) + K.RC;
@@ -284,8 +308,8 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         flags |= (best.G == G0 ? kDeferLoopEq : 0) | (((best.G < G0) & tie) ? kDeferLoopTie : 0);
         if (best.G < G0) {
             // exact enthalpy of the winning candidate from the compact tables
-            const CandGeom g = cand_geometry(c, best.W);
-            const int Hw = F.H[g.lx] + F.H[g.y] + (best.W >> 14) * 10;
+            const CandGeom g = cand_geometry(c, core_word(best.W));
+            const int Hw = F.H[g.lx] + F.H[g.y] + (best.W >> 16) * 10;
             // thal.c rejects a candidate with H > 0 and S > 0: never the case for a sensible
             // minimum; if it is, leave the pair to the f64 kernel
             flags |= ((Hw > 0) & (entropy_of(best.G, Hw) > -1e-6)) ? kDeferBad : 0;
@@ -295,7 +319,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         }
         defer |= slot < n_cells ? flags : 0;   // lanes past their last cell compute garbage
         // ---- publish the cell (idle lanes write a slot nobody reads)
-        store2(st, slot, G0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
+        store2(st, slot, G0, ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 4) | jm1);
         sh.pred[slot][threadIdx.x] = (unsigned char)pred;
     }
 
@@ -343,7 +367,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
                 const int slot = pc * kC + e;
                 const int pr = sh.pred[slot][threadIdx.x];
                 const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
-                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(W[e] & 0x3fff);
+                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(core_word(W[e]) & 0x3fff);
                 P += hit ? 1 : 0;
                 cur = hit ? pr : cur;
                 done = done | (hit & (pr == 0xff));
@@ -379,7 +403,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         }
     }
     // the replayed enthalpy must be the tracked one; anything else is handed on
-    defer |= (!out.r.none & (H != (pickW >> 14) * 10)) ? kDeferReplay : 0;
+    defer |= (!out.r.none & (H != (pickW >> 16) * 10)) ? kDeferReplay : 0;
     // ---- thal.c drawDimer(): totals
     {
         CellCtx cc;
