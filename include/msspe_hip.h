@@ -113,13 +113,14 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
 
 /* Diagnostics of the exact-integer first stage of the cross-dimer path since the last call
  * (engine-only, no reference counterpart): out[0] = pairs it handed to the f64 kernels because
- * Primer3's double comparisons could go either way, out[1..6] = how many of them met each reason
- * (Tm near-tie, loop == stack/start value, tie between loops, rejected minimum, tie in the
- * terminal pick, replay mismatch); out[7] = samples kept.  Reading resets the counters. */
+ * Primer3's double comparisons could go either way, out[1..7] = how many of them met each reason
+ * (Tm near-tie, loop == stack/start value with another enthalpy, tie between loops,
+ * rejected minimum, tie in the terminal pick, replay mismatch, equal-valued alternative on the
+ * optimal path).  Reading resets the counters. */
 int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8]);
 /* Up to 1024 of those pairs (call before msspe_pair_stage_stats, which resets the sample count):
  * out[i] = row << 40 | col << 16 | reason bits (1 Tm, 2 loop == value, 4 loop tie, 8 rejected
- * minimum, 16 pick tie, 32 replay). */
+ * minimum, 16 pick tie, 32 replay, 64 alternative on the path). */
 int msspe_pair_stage_samples(msspe_ctx *ctx, uint64_t *out, int capacity, int *n_out);
 /* Host only, no device: the folded tables the all-pairs kernels keep in LDS (csrc/fast_tables.hpp),
  * so that CPU tests can restate the integer recurrence.  fast_S / fast_H / int_g: 2604 entries,

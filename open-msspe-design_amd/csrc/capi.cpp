@@ -168,8 +168,8 @@ int ensure_overflow(msspe_ctx *ctx)
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (8 + 1024) * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (8 + 1024) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (9 + 1024) * sizeof(unsigned long long)));
     return MSSPE_OK;
 }
 
@@ -562,7 +562,7 @@ int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8])
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, 8 * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, 9 * sizeof(uint64_t)));
     return MSSPE_OK;
 }
 
@@ -574,9 +574,9 @@ int msspe_pair_stage_samples(msspe_ctx *ctx, uint64_t *out, int capacity, int *n
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t n = 0;
-    HIP_TRY(ctx, hipMemcpy(&n, ctx->d_reasons + 7, sizeof n, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&n, ctx->d_reasons + 8, sizeof n, hipMemcpyDeviceToHost));
     const int m = (int)std::min<uint64_t>(std::min<uint64_t>(n, 1024), (uint64_t)capacity);
-    if (m) HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons + 8, sizeof(uint64_t) * m, hipMemcpyDeviceToHost));
+    if (m) HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons + 9, sizeof(uint64_t) * m, hipMemcpyDeviceToHost));
     *n_out = m;
     return MSSPE_OK;
 }

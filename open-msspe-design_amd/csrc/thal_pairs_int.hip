@@ -50,6 +50,7 @@ struct SharedI {
     int T[IntTables::kRows * 64];
     Lds F;                              // f64 S + int H (replay, end terms)
     int g[FastTables::kCount];
+    double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
     unsigned char pred[kSlotsI][kThreadsI];
     unsigned short path[kPathMax][kThreadsI];
 };
@@ -118,18 +119,20 @@ __device__ __forceinline__ void fetch1(const ISlots &st, int pc, int (&W)[kC])
 #undef MSSPE_FETCH1
 }
 
-template <int PC = 0>
+// Publishes slot `slot` (wave-uniform): a branch tree over groups of four keeps every register
+// number a compile-time constant.
+template <int PG = 0>
 __device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
 {
-    if constexpr (PC < kNCh) {
-        if (slot < (PC + 1) * kC) {
+    if constexpr (PG * 4 < kSlotsI) {
+        if (slot < (PG + 1) * 4) {
             // the trailing asm differs per case, so the stores cannot be sunk into one indexed store
-#define MSSPE_ST(Q)                       \
-    st.G[PC * kC + Q] = G;                \
-    st.W[PC * kC + Q] = W;                \
-    asm volatile("" ::"n"(PC * kC + Q));  \
+#define MSSPE_ST(Q)                      \
+    st.G[PG * 4 + Q] = G;                \
+    st.W[PG * 4 + Q] = W;                \
+    asm volatile("" ::"n"(PG * 4 + Q));  \
     break;
-            switch (slot - PC * kC) {
+            switch (slot - PG * 4) {
             case 0: MSSPE_ST(0)
             case 1: MSSPE_ST(1)
             case 2: MSSPE_ST(2)
@@ -137,7 +140,7 @@ __device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
             }
 #undef MSSPE_ST
         } else {
-            store2<PC + 1>(st, slot, G, W);
+            store2<PG + 1>(st, slot, G, W);
         }
     }
 }
@@ -219,18 +222,13 @@ enum : int {
     kDeferBad = 8,       // the minimum has H > 0 and S > 0 (thal.c would reject it)
     kDeferPick = 16,     // two cells tie in the terminal pick
     kDeferReplay = 32,   // replayed enthalpy differs from the tracked one (never expected)
+    kDeferPathTie = 64,  // a cell of the optimal path has an equal-valued alternative
 };
 
 struct IntResult {
     PairResult r;
     int defer;   // not answered here: OR of the reasons above
 };
-
-// total entropy of a value from its exact (G, H): dG = H - 310.15 S and G = 2000 dG
-__device__ __forceinline__ double entropy_of(int G, int H)
-{
-    return ((double)H * 2000.0 - (double)G) * (1.0 / 620300.0);
-}
 
 // thal ANY for the lane's pair.  n_cells == 0: idle lane.
 __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
@@ -250,6 +248,9 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
     c.yTS = c.yMM = c.bBase = 0;
     unsigned Rrem = rowmask, mrem = 0;
     int im1 = 0, jm1 = 0;
+    int pickG = 0x7fffffff, pickW = 0;
+    bool pickTie = false;
+    unsigned long long softTie = 0ull;   // per lane: slots whose value has an equal-valued alternative
 
     for (int slot_ = 0; slot_ < nmax; ++slot_) {
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
@@ -284,19 +285,18 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
         const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
-        //      sides, so T1 > T0  <=>  A1 * B0 > A0 * B1.
+        //      sides, so T1 > T0 <=> A1 B0 > A0 B1; 620300 B = (2000 H - G) + cq (exact integers
+        //      plus one constant: decisive unless the two sides agree to 1e-9).
         int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
         if (stHave) {
-            const double rS = F.S[b.idxR];
             const int rH = F.H[b.idxR];
+            const double cq = sh.cq[b.idxR - FastTables::kEndR];
             const int H1 = (stk.W >> 16) * 10 + F.H[b.wc];
             const int G1 = stk.G + sh.g[b.wc];
             const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
-            const double B0 = ((entropy_of(G0, H0) + K.init_S) + rS) + K.RC;
-            const double B1 = ((entropy_of(G1, H1) + K.init_S) + rS) + K.RC;
+            const double B0 = (double)(2000 * H0 - G0) + cq, B1 = (double)(2000 * H1 - G1) + cq;
             const double lhs = A1 * B0, rhs = A0 * B1;
-            const bool sure = (B0 < 0.0) & (B1 < 0.0) &
-                              (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
+            const bool sure = (B0 < 0.0) & (B1 < 0.0) & (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
             flags |= sure ? 0 : kDeferTm;
             if (lhs > rhs) {
                 H0 = H1;
@@ -305,21 +305,41 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
             }
         }
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
-        flags |= (best.G == G0 ? kDeferLoopEq : 0) | (((best.G < G0) & tie) ? kDeferLoopTie : 0);
-        if (best.G < G0) {
-            // exact enthalpy of the winning candidate from the compact tables
+        if (best.G <= G0) {
+            // exact enthalpy of the best candidate from the compact tables
             const CandGeom g = cand_geometry(c, core_word(best.W));
             const int Hw = F.H[g.lx] + F.H[g.y] + (best.W >> 16) * 10;
-            // thal.c rejects a candidate with H > 0 and S > 0: never the case for a sensible
-            // minimum; if it is, leave the pair to the f64 kernel
-            flags |= ((Hw > 0) & (entropy_of(best.G, Hw) > -1e-6)) ? kDeferBad : 0;
-            H0 = Hw;
-            G0 = best.G;
-            pred = best.W & 0xff;
+            if (best.G < G0) {
+                // two candidates tie for the minimum: doubles could order them either way
+                flags |= tie ? kDeferLoopTie : 0;
+                // thal.c rejects a candidate with H > 0 and S > 0 (620300 S = 2000 H - G): never
+                // the case for a sensible minimum; if it is, leave the pair to the f64 kernel
+                flags |= ((Hw > 0) & (2000 * Hw - best.G > -1000)) ? kDeferBad : 0;
+                H0 = Hw;
+                G0 = best.G;
+                pred = best.W & 0xff;
+            } else if (Hw == H0) {
+                // same value either way: only the path (and the rounding along it) could differ
+                softTie |= (slot < n_cells) ? (1ull << slot) : 0ull;
+            } else {
+                flags |= kDeferLoopEq;
+            }
         }
-        defer |= slot < n_cells ? flags : 0;   // lanes past their last cell compute garbage
+        const int Wc = ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 4) | jm1;
+        const bool in = slot < n_cells;   // lanes past their last cell compute garbage
+        defer |= in ? flags : 0;
+        // ---- terminal pick (thal.c thal(): strict minimum of dG incl. the right end term, first
+        //      in row-major order = slot order; the 1e-6 nudges are the same on every cell and
+        //      drop out)
+        {
+            const int Gt = G0 + sh.g[b.idxR];
+            const bool pick = in & (Gt < pickG);
+            pickTie = pick ? false : (pickTie | (in & (Gt == pickG)));
+            pickG = pick ? Gt : pickG;
+            pickW = pick ? Wc : pickW;
+        }
         // ---- publish the cell (idle lanes write a slot nobody reads)
-        store2(st, slot, G0, ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 4) | jm1);
+        store2(st, slot, G0, Wc);
         sh.pred[slot][threadIdx.x] = (unsigned char)pred;
     }
 
@@ -329,28 +349,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
     out.r.t = 0.0;
     out.r.conflict = false;
 
-    // ---- terminal pick (thal.c thal(): strict minimum of dG incl. the right end term, first in
-    //      row-major order).  The 1e-6 nudges are the same on every cell and drop out.
-    int pickG = 0x7fffffff, pickW = 0;
-    bool pickTie = false;
     const int nch = (nmax + kC - 1) / kC;
-    for (int pc_ = 0; pc_ < nch; ++pc_) {
-        const int pc = __builtin_amdgcn_readfirstlane(pc_);
-        int G[kC], W[kC];
-        fetch2(st, pc, G, W);
-#pragma unroll
-        for (int e = 0; e < kC; ++e) {
-            const int slot = pc * kC + e;
-            CellCtx dummy;
-            const CellBases b = cell_bases(q, (W[e] >> 4) & 15, W[e] & 15, dummy);
-            const int Gt = G[e] + sh.g[b.idxR];
-            const bool in = slot < n_cells;
-            const bool pick = in & (Gt < pickG);
-            pickTie = pick ? false : (pickTie | (in & (Gt == pickG)));
-            pickG = pick ? Gt : pickG;
-            pickW = pick ? W[e] : pickW;
-        }
-    }
     defer |= pickTie ? kDeferPick : 0;
 
     // ---- traceback by pointer: path cells (end first) into the LDS scratch
@@ -368,6 +367,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
                 const int pr = sh.pred[slot][threadIdx.x];
                 const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
                 if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(core_word(W[e]) & 0x3fff);
+                defer |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
                 P += hit ? 1 : 0;
                 cur = hit ? pr : cur;
                 done = done | (hit & (pr == 0xff));
@@ -428,7 +428,8 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
 struct IntArgs {
     FastArgs f;
     const IntTables *it;
-    unsigned long long *reasons;   // optional statistics [8]: [0] pairs handed on, [1 + b] reason bit b
+    unsigned long long *reasons;   // optional statistics: [0] pairs handed on, [1 + b] reason bit b (b < 7),
+                                   // [8] samples kept, [9 ...] samples
 };
 
 __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
@@ -440,6 +441,8 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         sh.F.H[e] = a.f.ft->H[e];
         sh.g[e] = a.it->g[e];
     }
+    for (int e = threadIdx.x; e < 100; e += kThreadsI)
+        sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
     __syncthreads();
     ISlots st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -475,15 +478,15 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
             if (dm) {   // wave-uniform
                 if (lane == 0) atomicAdd(&a.reasons[0], (unsigned long long)__popcll(dm));
 #pragma unroll
-                for (int bit = 0; bit < 6; ++bit) {
+                for (int bit = 0; bit < 7; ++bit) {
                     const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
                     if (lane == 0 && bm) atomicAdd(&a.reasons[1 + bit], (unsigned long long)__popcll(bm));
                 }
                 // a few samples for diagnostics: row << 40 | col << 16 | reasons
-                if (deferred && a.reasons[7] < 1024ull) {
-                    const unsigned long long at = atomicAdd(&a.reasons[7], 1ull);
+                if (deferred && a.reasons[8] < 1024ull) {
+                    const unsigned long long at = atomicAdd(&a.reasons[8], 1ull);
                     if (at < 1024ull)
-                        a.reasons[8 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
+                        a.reasons[9 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
                                             (unsigned long long)r.defer;
                 }
             }

@@ -243,7 +243,7 @@ class Engine:
         v = (C.c_uint64 * 8)()
         self._check(self.L.msspe_pair_stage_stats(self.ptr, v))
         names = ("deferred", "tm_near_tie", "loop_eq_value", "loop_tie", "rejected_min", "pick_tie",
-                 "replay_mismatch")
+                 "replay_mismatch", "path_tie")
         return {n: int(v[i]) for i, n in enumerate(names)}
 
     # ---- stage B ---------------------------------------------------------------------------

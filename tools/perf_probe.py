@@ -30,12 +30,19 @@ def main():
         torch.cuda.synchronize()
         ovf = eng.last_overflow_pairs()
         stats = eng.pair_stage_stats()
+        import os
+        prof = os.environ.get('MSSPE_PROBE_PROFILE')
+        if prof: eng.profile_enable(True)
         t0 = time.time()
         reps = 2
         for _ in range(reps):
             run()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / reps
+        if prof:
+            nl, ms = eng.profile_read()
+            print(f'   first-stage launches {nl}, avg {ms/max(nl,1):.3f} ms per launch', flush=True)
+            eng.profile_enable(False)
         print(f"n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
               f"overflow pairs={ovf} ({100.0*ovf/(n*n):.2f} %)", flush=True)
         print("   integer stage:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats.items()}, flush=True)
