@@ -144,6 +144,7 @@ def main():
     launches, kernel_ms = eng.profile_read()
     eng.profile_enable(False)
     overflow = eng.last_overflow_pairs()
+    stage = eng.pair_stage_stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -154,7 +155,7 @@ def main():
 
     if rank == 0:
         conflicts = int(d_conf.sum().item())
-        # dominant kernel: k_pairs_fast; one launch covers up to 2^24 checks of this rank's block
+        # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^24 checks of this rank's block
         checks_rank = float(shard) * float(n) * args.steps
         per_launch_checks = checks_rank / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)
@@ -169,10 +170,22 @@ def main():
                 traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        int_stage = os.environ.get("MSSPE_PAIR_KERNEL", "") != "f64"
+        executed = None
+        pf = ROOT / "profiles" / "pmc_latest.json"
+        if pf.exists():
+            try:
+                executed = json.loads(pf.read_text())
+            except Exception:
+                executed = None
         roofline = {
             "bound": "valu",
-            "note": "FP64 vector-ALU bound DP: neither HBM nor MFMA binds it (SURVEY.md 8d); the hbm sub-object gives algorithmic bytes/s as the north star asks",
-            "kernel": "k_pairs_fast",
+            "note": ("vector-ALU bound DP: neither HBM nor MFMA binds it (SURVEY.md 8d). achieved = the "
+                     "reference recurrence's f64 operations per check (oracle count) x checks / kernel time, "
+                     "priced against the FP64 vector peak; the kernel itself runs the recurrence on exact "
+                     "int32 (see executed) and replays the optimal path in f64. hbm gives algorithmic "
+                     "bytes/s as the north star asks"),
+            "kernel": "k_pairs_int" if int_stage else "k_pairs_fast",
             "achieved": kernel_checks_per_s * F64_OPS_PER_CHECK / 1e12,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -182,6 +195,8 @@ def main():
             "launches": launches,
             "avg_launch_ms": per_launch_s * 1e3,
             "checks_per_launch": per_launch_checks,
+            "executed": executed,
+            "handed_to_f64_stages": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
             "hbm": {"achieved": bytes_per_launch / max(per_launch_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s",
                     "frac": bytes_per_launch / max(per_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBPS,
@@ -196,7 +211,7 @@ def main():
             "value": value, "unit": "checks/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "i32+f64", "data": "synthetic",
             "config": {"workload": f"cross-dimer all ordered pairs of {n} random 13-mers "
                                    f"({checks_per_step:.3g} checks/step), thal ANY at od-msspe defaults "
                                    f"(mv 50, dv 3, dNTP 0, 250 nM, 25 C), threshold -9000 cal/mol",

@@ -210,3 +210,33 @@ def test_large_pool_properties(eng, m, oracle, oracle_tables):
         _, _, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii, rows=(int(r), int(r) + 1), want_dg=False)
         np.testing.assert_array_equal(bits[r], cf[0])
     assert eng.last_overflow_pairs() > 0
+
+
+def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypatch):
+    """The exact-integer first stage (default) and the f64 register-table kernel
+    (MSSPE_PAIR_KERNEL=f64) must produce the same doubles and the same decisions; the integer
+    stage may hand only a small share of the pairs on, for the documented reasons."""
+    pool = m.synth.pool_strings(m.synth.random_pool(700, 13, seed=77))
+    chem = m.Chem.ntthal()
+    eng.pair_stage_stats()
+    a = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+    stats = eng.pair_stage_stats()
+    monkeypatch.setenv("MSSPE_PAIR_KERNEL", "f64")
+    b = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+    assert eng.pair_stage_stats()["deferred"] == 0          # the integer stage did not run
+    monkeypatch.delenv("MSSPE_PAIR_KERNEL")
+    for key in ("dg", "tm", "bitmap", "row_conflicts"):
+        np.testing.assert_array_equal(a[key], b[key])
+    n2 = len(pool) ** 2
+    assert 0 < stats["deferred"] < 0.06 * n2
+    assert stats["replay_mismatch"] == 0 and stats["tm_near_tie"] < 0.001 * n2
+    samples = eng.pair_stage_samples()
+    assert all(0 <= r < len(pool) and 0 <= c < len(pool) and bits for r, c, bits in samples)
+    # a few of the pairs that were handed on, against the oracle directly
+    oargs = oracle.ntthal_args()
+    for r, c, _bits in samples[:25]:
+        res = oracle.thal(oracle_tables, pool[r], pool[c], oracle.ANY, oargs)
+        if res.no_structure:
+            assert np.isinf(a["dg"][r, c])
+        else:
+            assert a["dg"][r, c] == res.dG and a["tm"][r, c] == res.t
