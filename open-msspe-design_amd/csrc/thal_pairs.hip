@@ -478,39 +478,108 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
     st.xW = &sh.X.W[0][threadIdx.x];
     st.xstride = THREADS;
     constexpr int NCH = NREG + NEXT;
+    // Lock-step lanes pay for the largest table of their wave, and a list arrives in no useful
+    // order: every block takes kListBatch * THREADS entries at a time and counting-sorts them by
+    // table size in LDS (the slot extension doubles as scratch), so that the 64 lanes of a wave
+    // get neighbours of the sorted batch.
+    constexpr int kListBatch = 4;
+    static_assert(sizeof(sh.X) >= sizeof(uint2) * kListBatch * THREADS + sizeof(unsigned) * 256,
+                  "the slot extension must hold one sorted batch");
+    uint2 *sorted = reinterpret_cast<uint2 *>(&sh.X);
+    unsigned *hist = reinterpret_cast<unsigned *>(sorted + kListBatch * THREADS);
     const long n_work = (long)min(*a.in_count, a.ovf_cap);
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long rounds = (n_work + stride - 1) / stride;
-    for (long rd = 0; rd < rounds; ++rd) {
-        const long w = first + rd * stride;
-        const bool inside = w < n_work;
-        const uint2 pr = a.in_list[inside ? w : 0];
-        const uint64_t pa = a.pool[pr.x], pb = a.pool[pr.y];
-        SeqPair q;
-        unsigned rowmask;
-        int n_cells = setup_pair(pa, pb, a.k, q, rowmask);
-        const bool sym = self_complementary(pa, a.k) && self_complementary(pb, a.k);
-        const bool spill = inside & ((n_cells > NCH * kChunk) | sym);
-        if (spill) {
-            const uint32_t at = atomicAdd(a.ovf_count, 1u);
-            if (at < a.ovf_cap) a.ovf_list[at] = pr;
+    const long batch = (long)kListBatch * THREADS;
+    const long n_batches = (n_work + batch - 1) / batch;
+    for (long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+        // ---- 1. keys and histogram
+        uint2 mine[kListBatch];
+        int key[kListBatch];
+        __threadfence_block();
+        for (int e = threadIdx.x; e < 256; e += THREADS) hist[e] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kListBatch; ++j) {
+            const long w = bt * batch + (long)j * THREADS + threadIdx.x;
+            const bool inside = w < n_work;
+            mine[j] = inside ? a.in_list[w] : make_uint2(0xffffffffu, 0u);
+            int nc = 255;   // padding entries sort last
+            if (inside) {
+                SeqPair q;
+                unsigned rowmask;
+                nc = min(setup_pair(a.pool[mine[j].x], a.pool[mine[j].y], a.k, q, rowmask), 254);
+            }
+            key[j] = nc;
+            atomicAdd(&hist[nc], 1u);
         }
-        if (!inside | spill) n_cells = 0;
-        const int nmax = wave_max(n_cells);
-        const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st);
-        if (inside & !spill) {
-            const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
-            const size_t ocol = (size_t)((int)pr.y - a.sinks.col0);
-            if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
-            if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
-            if (r.conflict) {
-                if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[pr.x], 1u);
-                if (a.sinks.bitmap)
-                    atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
-                             1ull << (ocol & 63));
+        __syncthreads();
+        // ---- 2. exclusive scan of the 256 bins (one wave)
+        if (threadIdx.x < 64) {
+            unsigned v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = hist[threadIdx.x * 4 + q];
+                sum += v[q];
+            }
+            unsigned incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hist[threadIdx.x * 4 + q] = run;
+                run += v[q];
             }
         }
+        __syncthreads();
+        // ---- 3. scatter into the sorted batch and write it back over the batch's own part of the
+        //         list (this block is its only reader), so that nothing is held in registers
+        //         across the DP
+#pragma unroll
+        for (int j = 0; j < kListBatch; ++j) sorted[atomicAdd(&hist[key[j]], 1u)] = mine[j];
+        __syncthreads();
+        uint2 *own = const_cast<uint2 *>(a.in_list) + bt * batch;
+        const long n_own = min(batch, n_work - bt * batch);
+#pragma unroll
+        for (int j = 0; j < kListBatch; ++j) {
+            const long e = (long)j * THREADS + threadIdx.x;
+            if (e < n_own) own[e] = sorted[e];   // padding entries sorted last
+        }
+        __syncthreads();   // the extension is the DP's again; the writes are visible to the block
+        // ---- 4. the pairs
+        for (int j = 0; j < kListBatch; ++j) {
+            const long e = (long)j * THREADS + threadIdx.x;
+            const bool inside = e < n_own;
+            const uint2 pr = own[inside ? e : 0];
+            const uint64_t pa = a.pool[inside ? pr.x : 0], pb = a.pool[inside ? pr.y : 0];
+            SeqPair q;
+            unsigned rowmask;
+            int n_cells = setup_pair(pa, pb, a.k, q, rowmask);
+            const bool sym = self_complementary(pa, a.k) && self_complementary(pb, a.k);
+            const bool spill = inside & ((n_cells > NCH * kChunk) | sym);
+            if (spill) {
+                const uint32_t at = atomicAdd(a.ovf_count, 1u);
+                if (at < a.ovf_cap) a.ovf_list[at] = pr;
+            }
+            if (!inside | spill) n_cells = 0;
+            const int nmax = wave_max(n_cells);
+            if (nmax == 0) continue;   // wave-uniform: nothing but padding / handed-on pairs
+            const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st);
+            if (inside & !spill) {
+                const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
+                const size_t ocol = (size_t)((int)pr.y - a.sinks.col0);
+                if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
+                if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
+                if (r.conflict) {
+                    if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[pr.x], 1u);
+                    if (a.sinks.bitmap)
+                        atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
+                                 1ull << (ocol & 63));
+                }
+            }
+        }
+        __syncthreads();   // before the next batch reuses the scratch
     }
 }
 
