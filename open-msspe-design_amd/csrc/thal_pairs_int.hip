@@ -119,30 +119,87 @@ __device__ __forceinline__ void fetch1(const ISlots &st, int pc, int (&W)[kC])
 #undef MSSPE_FETCH1
 }
 
-// Publishes slot `slot` (wave-uniform): a branch tree over groups of four keeps every register
-// number a compile-time constant.
-template <int PG = 0>
+// Publishes slot `slot` (wave-uniform).  One flat switch (a balanced tree of scalar compares):
+// every register number is a compile-time constant, and the trailing asm differs per case, so the
+// stores cannot be sunk into one dynamically indexed store (which would send the table to scratch).
 __device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
 {
-    if constexpr (PG * 4 < kSlotsI) {
-        if (slot < (PG + 1) * 4) {
-            // the trailing asm differs per case, so the stores cannot be sunk into one indexed store
-#define MSSPE_ST(Q)                      \
-    st.G[PG * 4 + Q] = G;                \
-    st.W[PG * 4 + Q] = W;                \
-    asm volatile("" ::"n"(PG * 4 + Q));  \
-    break;
-            switch (slot - PG * 4) {
-            case 0: MSSPE_ST(0)
-            case 1: MSSPE_ST(1)
-            case 2: MSSPE_ST(2)
-            default: MSSPE_ST(3)
-            }
-#undef MSSPE_ST
-        } else {
-            store2<PG + 1>(st, slot, G, W);
-        }
+#define MSSPE_ST(Q)                          \
+    case Q:                                  \
+        if constexpr (Q < kSlotsI) {         \
+            st.G[Q < kSlotsI ? Q : 0] = G;   \
+            st.W[Q < kSlotsI ? Q : 0] = W;   \
+            asm volatile("" ::"n"(Q));       \
+        }                                    \
+        break;
+    switch (slot) {
+    MSSPE_ST(0)
+    MSSPE_ST(1)
+    MSSPE_ST(2)
+    MSSPE_ST(3)
+    MSSPE_ST(4)
+    MSSPE_ST(5)
+    MSSPE_ST(6)
+    MSSPE_ST(7)
+    MSSPE_ST(8)
+    MSSPE_ST(9)
+    MSSPE_ST(10)
+    MSSPE_ST(11)
+    MSSPE_ST(12)
+    MSSPE_ST(13)
+    MSSPE_ST(14)
+    MSSPE_ST(15)
+    MSSPE_ST(16)
+    MSSPE_ST(17)
+    MSSPE_ST(18)
+    MSSPE_ST(19)
+    MSSPE_ST(20)
+    MSSPE_ST(21)
+    MSSPE_ST(22)
+    MSSPE_ST(23)
+    MSSPE_ST(24)
+    MSSPE_ST(25)
+    MSSPE_ST(26)
+    MSSPE_ST(27)
+    MSSPE_ST(28)
+    MSSPE_ST(29)
+    MSSPE_ST(30)
+    MSSPE_ST(31)
+    MSSPE_ST(32)
+    MSSPE_ST(33)
+    MSSPE_ST(34)
+    MSSPE_ST(35)
+    MSSPE_ST(36)
+    MSSPE_ST(37)
+    MSSPE_ST(38)
+    MSSPE_ST(39)
+    MSSPE_ST(40)
+    MSSPE_ST(41)
+    MSSPE_ST(42)
+    MSSPE_ST(43)
+    MSSPE_ST(44)
+    MSSPE_ST(45)
+    MSSPE_ST(46)
+    MSSPE_ST(47)
+    MSSPE_ST(48)
+    MSSPE_ST(49)
+    MSSPE_ST(50)
+    MSSPE_ST(51)
+    MSSPE_ST(52)
+    MSSPE_ST(53)
+    MSSPE_ST(54)
+    MSSPE_ST(55)
+    MSSPE_ST(56)
+    MSSPE_ST(57)
+    MSSPE_ST(58)
+    MSSPE_ST(59)
+    MSSPE_ST(60)
+    MSSPE_ST(61)
+    MSSPE_ST(62)
+    MSSPE_ST(63)
+    default: break;
     }
+#undef MSSPE_ST
 }
 
 // One predecessor slot against cell c.
