@@ -41,10 +41,22 @@ constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry
 // slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
 // (bits 8, 9 zero, so that bits 8..15 read as po * 4, a byte offset).  The predecessor of the
 // cell (im1 << 4 | jm1, 0xff: none) is only read by the traceback and lives in LDS.
-struct ISlots {
-    int G[kSlotsI];
-    int W[kSlotsI];
-};
+// The table is kept as register tuples (32 + 16 + 8 per plane), plain local values: reads use
+// compile-time element numbers, and the one write per cell goes through the wave-uniform slot
+// number (s_set_gpr_idx + v_mov), so publishing a cell needs no branch tree and no register copies.
+// (They must stay plain locals passed by value: behind a struct or a reference the compiler
+// leaves them in scratch memory.)
+typedef int v32i __attribute__((ext_vector_type(32)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+static_assert(kSlotsI == 56, "the tuples hold 32 + 16 + 8 slots");
+#define MSSPE_TAB_PARAMS const v32i Ga, const v32i Wa, const v16i Gb, const v16i Wb, const v8i Gc, const v8i Wc
+#define MSSPE_TAB_ARGS Ga, Wa, Gb, Wb, Gc, Wc
+
+__device__ __forceinline__ int slot_of(const v32i a, const v16i b, const v8i c, int x)
+{
+    return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
+}
 
 struct SharedI {
     int T[IntTables::kRows * 64];
@@ -71,135 +83,6 @@ struct IBest {
 __device__ __forceinline__ int core_word(int W)
 {
     return ((W >> 16) << 14) | ((W >> 2) & 0x3f00) | (W & 0xff);
-}
-
-// Keeps the cases of the chunk switches apart: without it the optimiser folds "case k: x = a[8k+q]"
-// into one dynamically indexed load, which sends the whole table to scratch memory.
-__device__ __forceinline__ int pin(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-__device__ __forceinline__ void fetch2(const ISlots &st, int pc, int (&G)[kC], int (&W)[kC])
-{
-#define MSSPE_FETCH2(PC)                                                       \
-    case PC:                                                                   \
-        if constexpr (PC < kNCh) {                                             \
-            _Pragma("unroll") for (int q = 0; q < kC; ++q) {                   \
-                G[q] = pin(st.G[(PC < kNCh ? PC : 0) * kC + q]);               \
-                W[q] = pin(st.W[(PC < kNCh ? PC : 0) * kC + q]);               \
-            }                                                                  \
-        }                                                                      \
-        break;
-    switch (pc) {
-        MSSPE_FETCH2(0) MSSPE_FETCH2(1) MSSPE_FETCH2(2) MSSPE_FETCH2(3) MSSPE_FETCH2(4) MSSPE_FETCH2(5)
-        MSSPE_FETCH2(6) MSSPE_FETCH2(7) MSSPE_FETCH2(8) MSSPE_FETCH2(9) MSSPE_FETCH2(10) MSSPE_FETCH2(11)
-        MSSPE_FETCH2(12) MSSPE_FETCH2(13) MSSPE_FETCH2(14) MSSPE_FETCH2(15)
-    default: break;
-    }
-#undef MSSPE_FETCH2
-}
-
-__device__ __forceinline__ void fetch1(const ISlots &st, int pc, int (&W)[kC])
-{
-#define MSSPE_FETCH1(PC)                                                       \
-    case PC:                                                                   \
-        if constexpr (PC < kNCh) {                                             \
-            _Pragma("unroll") for (int q = 0; q < kC; ++q)                     \
-                W[q] = pin(st.W[(PC < kNCh ? PC : 0) * kC + q]);               \
-        }                                                                      \
-        break;
-    switch (pc) {
-        MSSPE_FETCH1(0) MSSPE_FETCH1(1) MSSPE_FETCH1(2) MSSPE_FETCH1(3) MSSPE_FETCH1(4) MSSPE_FETCH1(5)
-        MSSPE_FETCH1(6) MSSPE_FETCH1(7) MSSPE_FETCH1(8) MSSPE_FETCH1(9) MSSPE_FETCH1(10) MSSPE_FETCH1(11)
-        MSSPE_FETCH1(12) MSSPE_FETCH1(13) MSSPE_FETCH1(14) MSSPE_FETCH1(15)
-    default: break;
-    }
-#undef MSSPE_FETCH1
-}
-
-// Publishes slot `slot` (wave-uniform).  One flat switch (a balanced tree of scalar compares):
-// every register number is a compile-time constant, and the trailing asm differs per case, so the
-// stores cannot be sunk into one dynamically indexed store (which would send the table to scratch).
-__device__ __forceinline__ void store2(ISlots &st, int slot, int G, int W)
-{
-#define MSSPE_ST(Q)                          \
-    case Q:                                  \
-        if constexpr (Q < kSlotsI) {         \
-            st.G[Q < kSlotsI ? Q : 0] = G;   \
-            st.W[Q < kSlotsI ? Q : 0] = W;   \
-            asm volatile("" ::"n"(Q));       \
-        }                                    \
-        break;
-    switch (slot) {
-    MSSPE_ST(0)
-    MSSPE_ST(1)
-    MSSPE_ST(2)
-    MSSPE_ST(3)
-    MSSPE_ST(4)
-    MSSPE_ST(5)
-    MSSPE_ST(6)
-    MSSPE_ST(7)
-    MSSPE_ST(8)
-    MSSPE_ST(9)
-    MSSPE_ST(10)
-    MSSPE_ST(11)
-    MSSPE_ST(12)
-    MSSPE_ST(13)
-    MSSPE_ST(14)
-    MSSPE_ST(15)
-    MSSPE_ST(16)
-    MSSPE_ST(17)
-    MSSPE_ST(18)
-    MSSPE_ST(19)
-    MSSPE_ST(20)
-    MSSPE_ST(21)
-    MSSPE_ST(22)
-    MSSPE_ST(23)
-    MSSPE_ST(24)
-    MSSPE_ST(25)
-    MSSPE_ST(26)
-    MSSPE_ST(27)
-    MSSPE_ST(28)
-    MSSPE_ST(29)
-    MSSPE_ST(30)
-    MSSPE_ST(31)
-    MSSPE_ST(32)
-    MSSPE_ST(33)
-    MSSPE_ST(34)
-    MSSPE_ST(35)
-    MSSPE_ST(36)
-    MSSPE_ST(37)
-    MSSPE_ST(38)
-    MSSPE_ST(39)
-    MSSPE_ST(40)
-    MSSPE_ST(41)
-    MSSPE_ST(42)
-    MSSPE_ST(43)
-    MSSPE_ST(44)
-    MSSPE_ST(45)
-    MSSPE_ST(46)
-    MSSPE_ST(47)
-    MSSPE_ST(48)
-    MSSPE_ST(49)
-    MSSPE_ST(50)
-    MSSPE_ST(51)
-    MSSPE_ST(52)
-    MSSPE_ST(53)
-    MSSPE_ST(54)
-    MSSPE_ST(55)
-    MSSPE_ST(56)
-    MSSPE_ST(57)
-    MSSPE_ST(58)
-    MSSPE_ST(59)
-    MSSPE_ST(60)
-    MSSPE_ST(61)
-    MSSPE_ST(62)
-    MSSPE_ST(63)
-    default: break;
-    }
-#undef MSSPE_ST
 }
 
 // One predecessor slot against cell c.
@@ -251,7 +134,7 @@ __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int 
 // compile-time register numbers and left through a wave-uniform branch at the first chunk that
 // holds no computed slot (later slots are empty and would fail the geometry test anyway).
 template <int PC = 0>
-__device__ __forceinline__ void scan_fill_int(const ISlots &st, int upto, const char *T, const ICell &c,
+__device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, const char *T, const ICell &c,
                                               IBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC < kNCh) {
@@ -260,13 +143,14 @@ __device__ __forceinline__ void scan_fill_int(const ISlots &st, int upto, const 
             Visit v[kC];
             int t[kC];
 #pragma unroll
-            for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, st.W[PC * kC + e]);
+            for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, slot_of(Wa, Wb, Wc, PC * kC + e));
 #pragma unroll
             for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
 #pragma unroll
             for (int e = 0; e < kC; ++e)
-                visit_finish(v[e], t[e], st.G[PC * kC + e], st.W[PC * kC + e], best, stk, m);
-            scan_fill_int<PC + 1>(st, upto, T, c, best, stk, m);
+                visit_finish(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e), best,
+                             stk, m);
+            scan_fill_int<PC + 1>(MSSPE_TAB_ARGS, upto, T, c, best, stk, m);
         }
     }
 }
@@ -289,14 +173,12 @@ struct IntResult {
 
 // thal ANY for the lane's pair.  n_cells == 0: idle lane.
 __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
-                                                  unsigned rowmask, int n_cells, int nmax, ISlots &st)
+                                                  unsigned rowmask, int n_cells, int nmax)
 {
     const Lds &F = sh.F;
-#pragma unroll
-    for (int x = 0; x < kSlotsI; ++x) {
-        st.G[x] = 0;
-        st.W[x] = kEmptyW;
-    }
+    v32i Ga = 0, Wa = kEmptyW;
+    v16i Gb = 0, Wb = kEmptyW;
+    v8i Gc = 0, Wc = kEmptyW;
     int defer = 0;
     CellCtx c;
     c.rS = 0.0;
@@ -338,7 +220,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
-        scan_fill_int(st, slot, (const char *)sh.T, ic, best, stk, sm);
+        scan_fill_int(MSSPE_TAB_ARGS, slot, (const char *)sh.T, ic, best, stk, sm);
         const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
         const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
@@ -382,7 +264,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
                 flags |= kDeferLoopEq;
             }
         }
-        const int Wc = ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 4) | jm1;
+        const int Wcell = ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 4) | jm1;
         const bool in = slot < n_cells;   // lanes past their last cell compute garbage
         defer |= in ? flags : 0;
         // ---- terminal pick (thal.c thal(): strict minimum of dG incl. the right end term, first
@@ -393,10 +275,19 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
             const bool pick = in & (Gt < pickG);
             pickTie = pick ? false : (pickTie | (in & (Gt == pickG)));
             pickG = pick ? Gt : pickG;
-            pickW = pick ? Wc : pickW;
+            pickW = pick ? Wcell : pickW;
         }
         // ---- publish the cell (idle lanes write a slot nobody reads)
-        store2(st, slot, G0, Wc);
+        if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
+            Ga[slot & 31] = G0;
+            Wa[slot & 31] = Wcell;
+        } else if (slot < 48) {
+            Gb[(slot - 32) & 15] = G0;
+            Wb[(slot - 32) & 15] = Wcell;
+        } else {
+            Gc[(slot - 48) & 7] = G0;
+            Wc[(slot - 48) & 7] = Wcell;
+        }
         sh.pred[slot][threadIdx.x] = (unsigned char)pred;
     }
 
@@ -417,7 +308,8 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
             const int pc = __builtin_amdgcn_readfirstlane(pc_);
             int W[kC];
-            fetch1(st, pc, W);
+#pragma unroll
+            for (int e = 0; e < kC; ++e) W[e] = slot_of(Wa, Wb, Wc, pc * kC + e);
 #pragma unroll
             for (int e = kC - 1; e >= 0; --e) {
                 const int slot = pc * kC + e;
@@ -501,7 +393,6 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
     for (int e = threadIdx.x; e < 100; e += kThreadsI)
         sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
     __syncthreads();
-    ISlots st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kRowsPerBlock = kThreadsI / 64;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
@@ -523,7 +414,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         bool spill = inside & ((n_cells > kSlotsI) | sym);
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max(n_cells);
-        const IntResult r = run_pair_int(sh, a.f.c, q, rowmask, n_cells, nmax, st);
+        const IntResult r = run_pair_int(sh, a.f.c, q, rowmask, n_cells, nmax);
         const bool deferred = inside & !spill & (r.defer != 0);
         spill |= deferred;
         if (spill) {
