@@ -116,6 +116,34 @@ __device__ __forceinline__ Visit visit_geometry(const ICell &c, int Wp)
     return v;
 }
 
+// The same for a slot that is known to lie at least three rows above the cell (l1 >= 2): no
+// stacked pair, no 1 x 1 loop, a bulge only through l2 = 0, and no row test.
+__device__ __forceinline__ Visit visit_geometry_far(const ICell &c, int Wp)
+{
+    Visit v;
+    const int d = c.cgeo - (Wp & 0xff);
+    const int jj = Wp & 15;
+    v.geo = jj <= c.jm1p;
+    v.stack = false;
+    const int po4 = (Wp >> 8) & 0xff;
+    const bool bulge = (d & 15) == 0;
+    const int pe4 = bulge ? ((po4 & 12) | c.a16) : po4;
+    v.idx4 = v.geo ? ((d << 8) | pe4) : 0;
+    v.y = bulge ? 0 : c.yTS;
+    return v;
+}
+
+__device__ __forceinline__ void visit_finish_far(const Visit &v, int t, int Gp, int Wp, IBest &best,
+                                                 ScanMasks &m)
+{
+    const int cand = t + v.y + Gp;
+    const bool better = cand < best.G;
+    const bool eq = cand == best.G;
+    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
+    best.G = better ? cand : best.G;
+    best.W = better ? Wp : best.W;
+}
+
 __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int Wp, IBest &best,
                                              IBest &stk, ScanMasks &m)
 {
@@ -134,25 +162,49 @@ __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int 
 // compile-time register numbers and left through a wave-uniform branch at the first chunk that
 // holds no computed slot (later slots are empty and would fail the geometry test anyway).
 template <int PC = 0>
-__device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, const char *T, const ICell &c,
-                                              IBest &best, IBest &stk, ScanMasks &m)
+__device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, int far_upto, const char *T,
+                                              const ICell &c, IBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC < kNCh) {
         if (PC * kC < upto) {   // wave-uniform
-            asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
             Visit v[kC];
             int t[kC];
+            if (PC * kC + kC <= far_upto) {   // wave-uniform: every lane has these slots >= 3 rows up
+                asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
 #pragma unroll
-            for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, slot_of(Wa, Wb, Wc, PC * kC + e));
+                for (int e = 0; e < kC; ++e) v[e] = visit_geometry_far(c, slot_of(Wa, Wb, Wc, PC * kC + e));
 #pragma unroll
-            for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
+                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
 #pragma unroll
-            for (int e = 0; e < kC; ++e)
-                visit_finish(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e), best,
-                             stk, m);
-            scan_fill_int<PC + 1>(MSSPE_TAB_ARGS, upto, T, c, best, stk, m);
+                for (int e = 0; e < kC; ++e)
+                    visit_finish_far(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e),
+                                     best, m);
+            } else {
+                asm volatile("" ::"n"(PC + 64));
+#pragma unroll
+                for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, slot_of(Wa, Wb, Wc, PC * kC + e));
+#pragma unroll
+                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
+#pragma unroll
+                for (int e = 0; e < kC; ++e)
+                    visit_finish(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e), best,
+                                 stk, m);
+            }
+            scan_fill_int<PC + 1>(MSSPE_TAB_ARGS, upto, far_upto, T, c, best, stk, m);
         }
     }
+}
+
+// Smallest value over the lanes of the wave for 0 <= v < 64: bisection on ballots (no LDS traffic).
+__device__ __forceinline__ int wave_min_64(int v)
+{
+    int lo = 0;   // answer is in [lo, lo + span)
+#pragma unroll
+    for (int span = 32; span > 0; span >>= 1) {
+        const bool below = v < lo + span;
+        lo += __builtin_amdgcn_ballot_w64(below) ? 0 : span;
+    }
+    return lo;
 }
 
 // why a pair is not answered here (bit mask; statistics in IntArgs::reasons)
@@ -187,6 +239,9 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
     c.yTS = c.yMM = c.bBase = 0;
     unsigned Rrem = rowmask, mrem = 0;
     int im1 = 0, jm1 = 0;
+    // first slot of the lane's current row and of its two previous non-empty rows: every slot
+    // below row_lo2 lies at least three rows above the current cell
+    int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
     int pickG = 0x7fffffff, pickW = 0;
     bool pickTie = false;
     unsigned long long softTie = 0ull;   // per lane: slots whose value has an equal-valued alternative
@@ -199,6 +254,9 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         const int a_new = (q.s1 >> (t & 31)) & 3;
         const unsigned m_new = spaced_mask(q.s2, 3 - a_new, q.lenmask);
         im1 = newrow ? (t >> 1) : im1;
+        row_lo2 = newrow ? row_lo1 : row_lo2;
+        row_lo1 = newrow ? row_lo0 : row_lo1;
+        row_lo0 = newrow ? slot : row_lo0;
         Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
         mrem = newrow ? m_new : mrem;
         jm1 = (__ffs((int)mrem) - 1) >> 1;
@@ -220,7 +278,8 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
-        scan_fill_int(MSSPE_TAB_ARGS, slot, (const char *)sh.T, ic, best, stk, sm);
+        const int far_upto = wave_min_64(slot < n_cells ? row_lo2 : 63);
+        scan_fill_int(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, ic, best, stk, sm);
         const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
         const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
