@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/profiles_raw/ (tools/collect_profiles.sh) into the tracked files under profiles/."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+RAW = ROOT / "gpurun_out" / "profiles_raw"
+OUT = ROOT / "profiles"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = "k_pairs_int"
+
+
+def pmc(sub):
+    tot = collections.defaultdict(list)
+    dur = []
+    for f in glob.glob(str(RAW / sub / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL not in r["Kernel_Name"]:
+                continue
+            tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    return ({k: sum(v) / len(v) for k, v in tot.items()}, (sum(dur) / len(dur) if dur else 0.0),
+            len(dur) // max(len(tot), 1))
+
+
+shutil.copy(RAW / "bench_stats" / "bench_kernel_stats.csv", OUT / f"{ROUND}_bench_kernel_stats.csv")
+shutil.copy(RAW / "stage_a_stats" / "stagea_kernel_stats.csv", OUT / f"{ROUND}_stage_a_kernel_stats.csv")
+line = [l for l in open(RAW / "bench_stdout.log") if l.startswith('{"metric"')][-1]
+(OUT / f"{ROUND}_bench_line.json").write_text(line)
+
+c1, ms1, n1 = pmc("pmc1")
+c2, ms2, n2 = pmc("pmc2")
+cf, msf, nf = pmc("pmc_fetch")
+cw, msw, nw = pmc("pmc_write")
+checks = 16777216.0
+waves = checks / 64.0
+clock_ghz = c2["GRBM_GUI_ACTIVE"] / 8.0 / (ms2 * 1e-3) / 1e9
+simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
+with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
+    f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 tools/perf_probe.py 16384 ; kernel {KERNEL},\n"
+            f"# mean per dispatch (2^24 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
+            f"# GRBM_GUI_ACTIVE sums the 8 XCDs (/8 = {c2['GRBM_GUI_ACTIVE']/8e6:.1f} M cycles in {ms2:.2f} ms = {clock_ghz:.2f} GHz)\n")
+    for name, (c, ms, n) in (("pass 1", (c1, ms1, n1)), ("pass 2", (c2, ms2, n2)), ("FETCH_SIZE [KB]", (cf, msf, nf)),
+                             ("WRITE_SIZE [KB]", (cw, msw, nw))):
+        f.write(f"## {name}: {n} dispatches, {ms:.3f} ms each\n")
+        for k in sorted(c):
+            f.write(f"{k:28s} {c[k]:.6g}\n")
+    f.write("## derived\n")
+    f.write(f"VALU instructions per check (per lane)      {c1['SQ_INSTS_VALU'] / waves:.0f}\n")
+    f.write(f"SALU / LDS / branch per wave-batch          {c1['SQ_INSTS_SALU'] / waves:.0f} / {c1['SQ_INSTS_LDS'] / waves:.0f} / {c1['SQ_INSTS_BRANCH'] / waves:.0f}\n")
+    f.write(f"VALU busy share of all SIMD issue slots     {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}\n")
+    f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
+hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
+(OUT / "traffic_latest.json").write_text(json.dumps({
+    "kernel": KERNEL, "round": int(ROUND[1:]),
+    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/perf_probe.py 16384",
+    "launches_sampled": nf,
+    "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
+    "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
+    "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
+    "note": "each launch covers 2^24 ordered pairs; traffic = table loads of the 1,024 persistent blocks (148 KB each, mostly L2 hits), "
+            "the 64-byte atomics that set conflict bits (0.5 % of pairs) and the list of pairs handed to the f64 stages (3.4 %, 8 B each); "
+            "algorithmic bytes per launch are about 2.6 MB"}, indent=1))
+(OUT / "pmc_latest.json").write_text(json.dumps({
+    "kernel": KERNEL, "source": f"profiles/{ROUND}_pmc_{KERNEL}.txt",
+    "valu_instructions_per_check": c1["SQ_INSTS_VALU"] / waves,
+    "salu_instructions_per_wave_batch": c1["SQ_INSTS_SALU"] / waves,
+    "lds_instructions_per_wave_batch": c1["SQ_INSTS_LDS"] / waves,
+    "valu_busy_fraction": c2["SQ_ACTIVE_INST_VALU"] / simd_quads,
+    "int32_valu_peak_tops": 256 * 4 * 16 * clock_ghz / 1e3,
+    "achieved_int32_tops": c1["SQ_INSTS_VALU"] * 64 / (ms1 * 1e-3) / 1e12,
+    "clock_ghz": clock_ghz}, indent=1))
+print(open(OUT / f"{ROUND}_pmc_{KERNEL}.txt").read())
