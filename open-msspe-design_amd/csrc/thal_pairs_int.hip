@@ -36,7 +36,7 @@ constexpr int kNCh = 14;           // chunks: 56 slots, all in VGPRs
 constexpr int kSlotsI = kC * kNCh;
 constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
-constexpr int kDragCost = 98;      // (slots^2 saved on 64 lanes) a lane must buy to be sent to the list stage
+constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned: flat from 25 to 50)
 constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
 
 // slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
@@ -476,8 +476,8 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         int nmax = wave_max(n_cells);
         // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes
         // far above the rest (mixed compositions at bin boundaries) are cheaper in the sorted f64
-        // list stage (about three integer-stage pairs each) than as a drag on 64 lanes.
-        for (int round = 0; round < 4; ++round) {
+        // list stage than as a drag on 64 lanes.
+        for (int round = 0; round < 6; ++round) {
             const int next = wave_max(n_cells < nmax ? n_cells : 0);
             const int m = __popcll(__ballot(n_cells == nmax));
             if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
