@@ -438,21 +438,29 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         a.col0 = 0;
         a.col1 = ncols;
         a.sinks = sinks;
-        // list A (ovf_list, counter 0) = what the first stage could not answer
+        // list A (ovf_list, counter 0) = what the first stage did not answer
         const uint2 *in_list = ctx->ovf_list;
         uint2 *out_list = ctx->ovf_list2;
         int in_c = 0, out_c = 1;
+        auto advance = [&]() {   // the two buffers ping-pong: a stage's input is consumed when it ends
+            in_list = out_list;
+            out_list = out_list == ctx->ovf_list2 ? ctx->ovf_list : ctx->ovf_list2;
+            in_c = out_c;
+            out_c = out_c + 1;
+        };
         if (int_stage) {
-            // the integer stage hands on ties as well as oversized tables: the 56-slot f64 table
-            // first, so that only the latter reach the wide kernel
+            // (1) the integer kernel again, 64 slots, lanes sorted by table size: pairs that only left
+            //     their wave because of their size; (2) the 56-slot f64 table: exact ties
             a.overflow_list = out_list;
             a.overflow_count = ctx->ovf_count + out_c;
             a.overflow_cap = (uint32_t)kListCap;
+            HIP_TRY(ctx, launch_pairs_int_list(a, ce->d_it, in_list, ctx->ovf_count + in_c, ctx->d_reasons,
+                                               ctx->stream));
+            advance();
+            a.overflow_list = out_list;
+            a.overflow_count = ctx->ovf_count + out_c;
             HIP_TRY(ctx, launch_pairs_main_list(a, in_list, ctx->ovf_count + in_c, ctx->stream));
-            in_list = ctx->ovf_list2;
-            out_list = ctx->ovf_list;   // list A is consumed by now
-            in_c = 1;
-            out_c = 2;
+            advance();
         }
         // the wide table over the list
         a.overflow_list = out_list;

@@ -90,6 +90,10 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
 // counters [8] ([0] = pairs handed on because of a tie, [1 + b] = reason bit b, see the kernel).
 hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
                             hipStream_t stream);
+// List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit
+// 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
+hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
+                                 const uint32_t *in_count, unsigned long long *reasons, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();

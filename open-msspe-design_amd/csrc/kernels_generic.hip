@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_dimer_generic(GenericDimerArgs a)
         if (a.self_mode) {
             row = col = (int)w;
         } else if (a.list) {
-            row = (int)a.list[w].x;
+            row = (int)(a.list[w].x & 0x7fffffffu);   // bit 31: mark of the integer stage
             col = (int)a.list[w].y;
         } else {
             row = a.sinks.row0 + (int)(w / a.sinks.ncols);

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
             if (inside) {
                 SeqPair q;
                 unsigned rowmask;
-                nc = min(setup_pair(a.pool[mine[j].x], a.pool[mine[j].y], a.k, q, rowmask), 254);
+                nc = min(setup_pair(a.pool[mine[j].x & 0x7fffffffu], a.pool[mine[j].y], a.k, q, rowmask), 254);
             }
             key[j] = nc;
             atomicAdd(&hist[nc], 1u);
@@ -551,7 +551,8 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
         for (int j = 0; j < kListBatch; ++j) {
             const long e = (long)j * THREADS + threadIdx.x;
             const bool inside = e < n_own;
-            const uint2 pr = own[inside ? e : 0];
+            uint2 pr = own[inside ? e : 0];
+            pr.x &= 0x7fffffffu;   // bit 31: "needs the f64 kernels" mark of the integer stage
             const uint64_t pa = a.pool[inside ? pr.x : 0], pb = a.pool[inside ? pr.y : 0];
             SeqPair q;
             unsigned rowmask;

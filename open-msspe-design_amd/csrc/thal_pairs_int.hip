@@ -32,8 +32,9 @@ namespace msspe {
 namespace {
 
 constexpr int kC = 4;              // slots per chunk (= predecessor evaluations in flight)
-constexpr int kNCh = 14;           // chunks: 56 slots, all in VGPRs
-constexpr int kSlotsI = kC * kNCh;
+constexpr int kSlotsMatrix = 56;   // table of the matrix-mode kernel (the largest tables drag their waves)
+constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
+constexpr int kSlotsMax = 64;      // register tuples and LDS rows are sized for this
 constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
 constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned: flat from 25 to 50)
@@ -42,21 +43,37 @@ constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry
 // slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
 // (bits 8, 9 zero, so that bits 8..15 read as po * 4, a byte offset).  The predecessor of the
 // cell (im1 << 4 | jm1, 0xff: none) is only read by the traceback and lives in LDS.
-// The table is kept as register tuples (32 + 16 + 8 per plane), plain local values: reads use
-// compile-time element numbers, and the one write per cell goes through the wave-uniform slot
-// number (s_set_gpr_idx + v_mov), so publishing a cell needs no branch tree and no register copies.
-// (They must stay plain locals passed by value: behind a struct or a reference the compiler
-// leaves them in scratch memory.)
+// The table is kept as register tuples, plain local values (32 + 16 + 8 elements per plane for 56
+// slots, 32 + 32 for 64): reads use compile-time element numbers, and the one write per cell goes
+// through the wave-uniform slot number (s_set_gpr_idx + v_mov), so publishing a cell needs no
+// branch tree and no register copies.  (They must stay plain locals passed by value: behind a
+// struct or a reference the compiler leaves them in scratch memory.)
 typedef int v32i __attribute__((ext_vector_type(32)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v8i __attribute__((ext_vector_type(8)));
-static_assert(kSlotsI == 56, "the tuples hold 32 + 16 + 8 slots");
-#define MSSPE_TAB_PARAMS const v32i Ga, const v32i Wa, const v16i Gb, const v16i Wb, const v8i Gc, const v8i Wc
+template <int NS>
+struct TabTypes;
+template <>
+struct TabTypes<56> {
+    typedef v16i B;
+    typedef v8i C;
+};
+template <>
+struct TabTypes<64> {
+    typedef v32i B;
+    typedef v8i C;   // unused
+};
+#define MSSPE_TAB_PARAMS                                                                                   \
+    const v32i Ga, const v32i Wa, const typename TabTypes<NS>::B Gb, const typename TabTypes<NS>::B Wb, \
+        const typename TabTypes<NS>::C Gc, const typename TabTypes<NS>::C Wc
 #define MSSPE_TAB_ARGS Ga, Wa, Gb, Wb, Gc, Wc
 
-__device__ __forceinline__ int slot_of(const v32i a, const v16i b, const v8i c, int x)
+template <int NS>
+__device__ __forceinline__ int slot_of(const v32i a, const typename TabTypes<NS>::B b,
+                                       const typename TabTypes<NS>::C c, int x)
 {
-    return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
+    if constexpr (NS == 56) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
+    else return x < 32 ? a[x & 31] : b[(x - 32) & 31];
 }
 
 struct SharedI {
@@ -64,7 +81,7 @@ struct SharedI {
     Lds F;                              // f64 S + int H (replay, end terms)
     int g[FastTables::kCount];
     double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
-    unsigned char pred[kSlotsI][kThreadsI];
+    unsigned char pred[kSlotsMax][kThreadsI];
     unsigned short path[kPathMax][kThreadsI];
 };
 
@@ -162,36 +179,36 @@ __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int 
 // All earlier slots as predecessors of cell c, kC at a time.  The chunks are unrolled with
 // compile-time register numbers and left through a wave-uniform branch at the first chunk that
 // holds no computed slot (later slots are empty and would fail the geometry test anyway).
-template <int PC = 0>
+template <int NS, int PC = 0>
 __device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, int far_upto, const char *T,
                                               const ICell &c, IBest &best, IBest &stk, ScanMasks &m)
 {
-    if constexpr (PC < kNCh) {
+    if constexpr (PC * kC < NS) {
         if (PC * kC < upto) {   // wave-uniform
             Visit v[kC];
             int t[kC];
             if (PC * kC + kC <= far_upto) {   // wave-uniform: every lane has these slots >= 3 rows up
                 asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
 #pragma unroll
-                for (int e = 0; e < kC; ++e) v[e] = visit_geometry_far(c, slot_of(Wa, Wb, Wc, PC * kC + e));
+                for (int e = 0; e < kC; ++e) v[e] = visit_geometry_far(c, slot_of<NS>(Wa, Wb, Wc, PC * kC + e));
 #pragma unroll
                 for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
 #pragma unroll
                 for (int e = 0; e < kC; ++e)
-                    visit_finish_far(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e),
+                    visit_finish_far(v[e], t[e], slot_of<NS>(Ga, Gb, Gc, PC * kC + e), slot_of<NS>(Wa, Wb, Wc, PC * kC + e),
                                      best, m);
             } else {
                 asm volatile("" ::"n"(PC + 64));
 #pragma unroll
-                for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, slot_of(Wa, Wb, Wc, PC * kC + e));
+                for (int e = 0; e < kC; ++e) v[e] = visit_geometry(c, slot_of<NS>(Wa, Wb, Wc, PC * kC + e));
 #pragma unroll
                 for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + v[e].idx4);
 #pragma unroll
                 for (int e = 0; e < kC; ++e)
-                    visit_finish(v[e], t[e], slot_of(Ga, Gb, Gc, PC * kC + e), slot_of(Wa, Wb, Wc, PC * kC + e), best,
+                    visit_finish(v[e], t[e], slot_of<NS>(Ga, Gb, Gc, PC * kC + e), slot_of<NS>(Wa, Wb, Wc, PC * kC + e), best,
                                  stk, m);
             }
-            scan_fill_int<PC + 1>(MSSPE_TAB_ARGS, upto, far_upto, T, c, best, stk, m);
+            scan_fill_int<NS, PC + 1>(MSSPE_TAB_ARGS, upto, far_upto, T, c, best, stk, m);
         }
     }
 }
@@ -225,13 +242,14 @@ struct IntResult {
 };
 
 // thal ANY for the lane's pair.  n_cells == 0: idle lane.
+template <int NS>
 __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
                                                   unsigned rowmask, int n_cells, int nmax)
 {
     const Lds &F = sh.F;
     v32i Ga = 0, Wa = kEmptyW;
-    v16i Gb = 0, Wb = kEmptyW;
-    v8i Gc = 0, Wc = kEmptyW;
+    typename TabTypes<NS>::B Gb = 0, Wb = kEmptyW;
+    typename TabTypes<NS>::C Gc = 0, Wc = kEmptyW;
     int defer = 0;
     CellCtx c;
     c.rS = 0.0;
@@ -280,7 +298,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
         const int far_upto = wave_min_64(slot < n_cells ? row_lo2 : 63);
-        scan_fill_int(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, ic, best, stk, sm);
+        scan_fill_int<NS>(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, ic, best, stk, sm);
         const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
         const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
@@ -341,12 +359,17 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0;
             Wa[slot & 31] = Wcell;
-        } else if (slot < 48) {
-            Gb[(slot - 32) & 15] = G0;
-            Wb[(slot - 32) & 15] = Wcell;
+        } else if constexpr (NS == 56) {
+            if (slot < 48) {
+                Gb[(slot - 32) & 15] = G0;
+                Wb[(slot - 32) & 15] = Wcell;
+            } else {
+                Gc[(slot - 48) & 7] = G0;
+                Wc[(slot - 48) & 7] = Wcell;
+            }
         } else {
-            Gc[(slot - 48) & 7] = G0;
-            Wc[(slot - 48) & 7] = Wcell;
+            Gb[(slot - 32) & 31] = G0;
+            Wb[(slot - 32) & 31] = Wcell;
         }
         sh.pred[slot][threadIdx.x] = (unsigned char)pred;
     }
@@ -369,7 +392,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
             const int pc = __builtin_amdgcn_readfirstlane(pc_);
             int W[kC];
 #pragma unroll
-            for (int e = 0; e < kC; ++e) W[e] = slot_of(Wa, Wb, Wc, pc * kC + e);
+            for (int e = 0; e < kC; ++e) W[e] = slot_of<NS>(Wa, Wb, Wc, pc * kC + e);
 #pragma unroll
             for (int e = kC - 1; e >= 0; --e) {
                 const int slot = pc * kC + e;
@@ -392,13 +415,13 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
             const int step = __builtin_amdgcn_readfirstlane(step_);
             const int e = P - 1 - step;
             if (e >= 0) {
-                const int Wc = sh.path[e & (kPathMax - 1)][threadIdx.x];
+                const int Wstep = sh.path[e & (kPathMax - 1)][threadIdx.x];
                 CellCtx cc;
-                const CellBases b = cell_bases(q, (Wc >> 4) & 15, Wc & 15, cc);
+                const CellBases b = cell_bases(q, (Wstep >> 4) & 15, Wstep & 15, cc);
                 if (step == 0) {
                     S = F.S[b.idxL];
                     H = F.H[b.idxL];
-                } else if (((Wc & 0xff) - (prevW & 0xff)) == 0x11) {
+                } else if (((Wstep & 0xff) - (prevW & 0xff)) == 0x11) {
                     S = S + F.S[b.wc];
                     H = H + F.H[b.wc];
                 } else {
@@ -407,7 +430,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
                     S = ((v.sLX + v.sY) + v.sZ) + S;
                     H = v.hLX + v.hY + H;
                 }
-                prevW = Wc;
+                prevW = Wstep;
             }
         }
     }
@@ -441,9 +464,12 @@ struct IntArgs {
                                    // [8] samples kept, [9 ...] samples
 };
 
-__global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
+// A list entry whose pair needs the f64 kernels (an exact tie was met) carries this bit in .x;
+// entries without it only left their wave because of their table size and may be retried here.
+constexpr unsigned kNeedsF64 = 0x80000000u;
+
+__device__ __forceinline__ void load_tables_int(SharedI &sh, const IntArgs &a)
 {
-    __shared__ SharedI sh;
     for (int e = threadIdx.x; e < IntTables::kRows * 64; e += kThreadsI) sh.T[e] = a.it->T[e];
     for (int e = threadIdx.x; e < FastTables::kCount; e += kThreadsI) {
         sh.F.S[e] = a.f.ft->S[e];
@@ -453,6 +479,97 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
     for (int e = threadIdx.x; e < 100; e += kThreadsI)
         sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
     __syncthreads();
+}
+
+// One lock-step DP of the wave: lane = pair (row, col); `take` lanes are computed, `pass_on`
+// lanes go to the output list untouched (flag kept).  same_row: all lanes share `row`.
+template <int NS>
+__device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int row, int col, uint64_t pa,
+                                           uint64_t pb, bool inside, bool pass_on, unsigned pass_flag,
+                                           bool same_row)
+{
+    const int lane = threadIdx.x & 63;
+    SeqPair q;
+    unsigned rowmask;
+    int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
+    const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
+    bool spill = inside & (pass_on | (n_cells > NS) | sym);
+    unsigned flag = pass_on ? pass_flag : 0u;
+    if (!inside | spill) n_cells = 0;
+    int nmax = wave_max(n_cells);
+    // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes
+    // far above the rest (mixed compositions at bin boundaries) are cheaper in a sorted list
+    // stage than as a drag on 64 lanes.
+    for (int round = 0; round < 6; ++round) {
+        const int next = wave_max(n_cells < nmax ? n_cells : 0);
+        const int m = __popcll(__ballot(n_cells == nmax));
+        if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
+        if (n_cells == nmax) {
+            spill = true;
+            n_cells = 0;
+        }
+        nmax = next;
+    }
+    if (nmax == 0) {   // wave-uniform: nothing to compute
+        if (spill) {
+            const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
+            if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
+        }
+        return;
+    }
+    const IntResult r = run_pair_int<NS>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const bool deferred = inside & !spill & (r.defer != 0);
+    if (deferred) flag = kNeedsF64;
+    spill |= deferred;
+    if (spill) {
+        const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
+        if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
+    }
+    if (a.reasons) {
+        const unsigned long long dm = __ballot(deferred);
+        if (dm) {   // wave-uniform
+            if (lane == 0) atomicAdd(&a.reasons[0], (unsigned long long)__popcll(dm));
+#pragma unroll
+            for (int bit = 0; bit < 7; ++bit) {
+                const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
+                if (lane == 0 && bm) atomicAdd(&a.reasons[1 + bit], (unsigned long long)__popcll(bm));
+            }
+            // a few samples for diagnostics: row << 40 | col << 16 | reasons
+            if (deferred && a.reasons[8] < 1024ull) {
+                const unsigned long long at = atomicAdd(&a.reasons[8], 1ull);
+                if (at < 1024ull)
+                    a.reasons[9 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
+                                        (unsigned long long)r.defer;
+            }
+        }
+    }
+    // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
+    const bool live = inside & !spill;
+    const bool hit = live & r.r.conflict;
+    const size_t orow = (size_t)(row - a.f.sinks.row0);
+    const size_t ocol = (size_t)(col - a.f.sinks.col0);
+    if (hit && a.f.sinks.bitmap)
+        atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
+                 1ull << (ocol & 63));
+    if (a.f.sinks.row_conflicts) {
+        if (same_row) {
+            const unsigned long long bits = __ballot(hit);
+            if (lane == 0 && bits) atomicAdd(&a.f.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+        } else if (hit) {
+            atomicAdd(&a.f.sinks.row_conflicts[row], 1u);
+        }
+    }
+    if (live) {
+        if (a.f.sinks.dg) a.f.sinks.dg[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.dG;
+        if (a.f.sinks.tm) a.f.sinks.tm[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.t;
+    }
+}
+
+// Matrix mode: wave = one row x 64 consecutive entries of the composition-sorted column list.
+__global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
+{
+    __shared__ SharedI sh;
+    load_tables_int(sh, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kRowsPerBlock = kThreadsI / 64;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
@@ -467,73 +584,96 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         const uint64_t pa = a.f.pool[row];
         const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
         const int col = (int)a.f.perm[inside ? cq : a.f.col0];
-        SeqPair q;
-        unsigned rowmask;
-        int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
-        const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
-        bool spill = inside & ((n_cells > kSlotsI) | sym);
-        if (!inside | spill) n_cells = 0;
-        int nmax = wave_max(n_cells);
-        // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes
-        // far above the rest (mixed compositions at bin boundaries) are cheaper in the sorted f64
-        // list stage than as a drag on 64 lanes.
-        for (int round = 0; round < 6; ++round) {
-            const int next = wave_max(n_cells < nmax ? n_cells : 0);
-            const int m = __popcll(__ballot(n_cells == nmax));
-            if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
-            const bool out_ = n_cells == nmax;
-            if (out_) {
-                spill = true;
-                n_cells = 0;
-            }
-            nmax = next;
-        }
-        const IntResult r = run_pair_int(sh, a.f.c, q, rowmask, n_cells, nmax);
-        const bool deferred = inside & !spill & (r.defer != 0);
-        spill |= deferred;
-        if (spill) {
-            const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
-            if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
-        }
-        if (a.reasons) {
-            const unsigned long long dm = __ballot(deferred);
-            if (dm) {   // wave-uniform
-                if (lane == 0) atomicAdd(&a.reasons[0], (unsigned long long)__popcll(dm));
+        wave_pairs<kSlotsMatrix>(sh, a, row, col, pa, pb, inside, false, 0u, true);
+    }
+}
+
+// List mode: the pairs the matrix-mode kernel sent away because of their table size get a second
+// chance in lanes sorted by table size (64 slots); entries flagged kNeedsF64 and what still does
+// not fit pass through to the output list.  Batches of kListBatchI x 512 entries are
+// counting-sorted in LDS (the predecessor rows double as scratch) and written back in place.
+constexpr int kListBatchI = 4;
+__global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
+{
+    __shared__ SharedI sh;
+    load_tables_int(sh, a);
+    static_assert(sizeof(sh.pred) >= sizeof(uint2) * kListBatchI * kThreadsI + sizeof(unsigned) * 256,
+                  "the predecessor rows must hold one sorted batch");
+    uint2 *sorted = reinterpret_cast<uint2 *>(&sh.pred[0][0]);
+    unsigned *hist = reinterpret_cast<unsigned *>(sorted + kListBatchI * kThreadsI);
+    const long n_work = (long)min(*a.f.in_count, a.f.ovf_cap);
+    const long batch = (long)kListBatchI * kThreadsI;
+    const long n_batches = (n_work + batch - 1) / batch;
+    for (long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+        uint2 mine[kListBatchI];
+        int key[kListBatchI];
+        for (int e = threadIdx.x; e < 256; e += kThreadsI) hist[e] = 0u;
+        __syncthreads();
 #pragma unroll
-                for (int bit = 0; bit < 7; ++bit) {
-                    const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
-                    if (lane == 0 && bm) atomicAdd(&a.reasons[1 + bit], (unsigned long long)__popcll(bm));
-                }
-                // a few samples for diagnostics: row << 40 | col << 16 | reasons
-                if (deferred && a.reasons[8] < 1024ull) {
-                    const unsigned long long at = atomicAdd(&a.reasons[8], 1ull);
-                    if (at < 1024ull)
-                        a.reasons[9 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
-                                            (unsigned long long)r.defer;
+        for (int j = 0; j < kListBatchI; ++j) {
+            const long w = bt * batch + (long)j * kThreadsI + threadIdx.x;
+            const bool inside = w < n_work;
+            mine[j] = inside ? a.f.in_list[w] : make_uint2(0xffffffffu, 0u);
+            int nc = 255;   // padding sorts last, pass-through entries just before it
+            if (inside) {
+                nc = 254;
+                if (!(mine[j].x & kNeedsF64)) {
+                    SeqPair q;
+                    unsigned rowmask;
+                    nc = min(setup_pair(a.f.pool[mine[j].x], a.f.pool[mine[j].y], a.f.k, q, rowmask), 253);
                 }
             }
+            key[j] = nc;
+            atomicAdd(&hist[nc], 1u);
         }
-        // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
-        const bool live = inside & !spill;
-        const bool hit = live & r.r.conflict;
-        const unsigned long long bits = __ballot(hit);
-        const size_t orow = (size_t)(row - a.f.sinks.row0);
-        const size_t ocol = (size_t)(col - a.f.sinks.col0);
-        if (hit && a.f.sinks.bitmap)
-            atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
-                     1ull << (ocol & 63));
-        if (lane == 0 && a.f.sinks.row_conflicts && bits)
-            atomicAdd(&a.f.sinks.row_conflicts[row], (unsigned)__popcll(bits));
-        if (live) {
-            if (a.f.sinks.dg) a.f.sinks.dg[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.dG;
-            if (a.f.sinks.tm) a.f.sinks.tm[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.t;
+        __syncthreads();
+        if (threadIdx.x < 64) {   // exclusive scan of the 256 bins
+            unsigned v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = hist[threadIdx.x * 4 + q];
+                sum += v[q];
+            }
+            unsigned incl = sum;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hist[threadIdx.x * 4 + q] = run;
+                run += v[q];
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kListBatchI; ++j) sorted[atomicAdd(&hist[key[j]], 1u)] = mine[j];
+        __syncthreads();
+        uint2 *own = const_cast<uint2 *>(a.f.in_list) + bt * batch;
+        const long n_own = min(batch, n_work - bt * batch);
+#pragma unroll
+        for (int j = 0; j < kListBatchI; ++j) {
+            const long e = (long)j * kThreadsI + threadIdx.x;
+            if (e < n_own) own[e] = sorted[e];
+        }
+        __syncthreads();   // the predecessor rows are the DP's again; the writes are visible to the block
+        for (int j = 0; j < kListBatchI; ++j) {
+            const long e = (long)j * kThreadsI + threadIdx.x;
+            const bool inside = e < n_own;
+            const uint2 pr = own[inside ? e : 0];
+            const bool pass_on = (pr.x & kNeedsF64) != 0u;
+            const int row = (int)(pr.x & ~kNeedsF64), col = (int)pr.y;
+            wave_pairs<kSlotsList>(sh, a, row, col, a.f.pool[inside ? row : 0], a.f.pool[inside ? col : 0], inside,
+                                   pass_on, kNeedsF64, false);
+        }
+        __syncthreads();
     }
 }
 
 }  // namespace
 
-int pairs_int_slots() { return kSlotsI; }
+int pairs_int_slots() { return kSlotsMatrix; }
 
 hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
                             hipStream_t stream)
@@ -564,6 +704,33 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L * 4 ? tiles : 256L * 4);
     hipLaunchKernelGGL(k_pairs_int, dim3(grid), dim3(kThreadsI), 0, stream, x);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
+                                 const uint32_t *in_count, unsigned long long *reasons, hipStream_t stream)
+{
+    IntArgs x;
+    FastArgs &f = x.f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.cols_sorted = nullptr;
+    f.perm = nullptr;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = in_list;
+    f.in_count = in_count;
+    x.it = it;
+    x.reasons = reasons;
+    hipLaunchKernelGGL(k_pairs_int_list, dim3(256 * 2), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }
 
