@@ -40,7 +40,8 @@ struct ChemEntry {
 };
 
 constexpr long kChunkPairs = 1L << 24;       // pairs per launch of the all-pairs kernel
-constexpr long kListCap = 1L << 27;          // overflow-list entries: 8 launches can never overrun it
+constexpr long kListCapMin = 1L << 24;       // hand-over list entries: one launch can never overrun it
+constexpr long kListCapMax = 1L << 29;       // 4 GB per list: 32 launches between flushes (288 GB HBM)
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace
@@ -57,6 +58,7 @@ struct msspe_ctx {
     uint2 *ovf_list = nullptr;         // pairs the main kernel could not hold
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
     uint32_t *ovf_count = nullptr;     // list counters of the stages: [0] first, [1] second, [2] third
+    long list_cap = 0;                 // entries per hand-over list
     uint64_t *d_ovf_total = nullptr;
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
@@ -159,11 +161,32 @@ int ensure_workspace(msspe_ctx *ctx, size_t cells_per_lane)
     return MSSPE_OK;
 }
 
-int ensure_overflow(msspe_ctx *ctx)
+// The lists are sized by the call (every pair could be handed on between two flushes): small
+// screens keep small lists, the 65,536-primer screen flushes every 32 launches.
+int ensure_overflow(msspe_ctx *ctx, long total_pairs)
 {
-    if (ctx->ovf_list) return MSSPE_OK;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)kListCap));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)kListCap));
+    long want = kListCapMin;
+    while (want < total_pairs && want < kListCapMax) want <<= 1;
+    if (const char *e = std::getenv("MSSPE_LIST_CAP_LOG2")) {   // testing aid: force flushes mid-screen
+        const long lg = std::strtol(e, nullptr, 10);
+        if (lg >= 24 && lg <= 29) want = 1L << lg;
+    }
+    if (ctx->ovf_list && (ctx->list_cap == want || (ctx->list_cap > want && !std::getenv("MSSPE_LIST_CAP_LOG2"))))
+        return MSSPE_OK;
+    if (ctx->ovf_list) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ovf_list);
+        (void)hipFree(ctx->ovf_list2);
+        ctx->ovf_list = ctx->ovf_list2 = nullptr;
+        ctx->list_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want));
+        ctx->list_cap = want;
+        return MSSPE_OK;
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want));
+    ctx->list_cap = want;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
@@ -367,7 +390,8 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     int rc = chem_entry(ctx, *chem, dg_threshold, &ce);
     if (rc) return rc;
     if ((rc = ensure_workspace(ctx, (size_t)k * (size_t)k))) return rc;
-    if ((rc = ensure_overflow(ctx))) return rc;
+    if ((rc = ensure_overflow(ctx, (long)(row1 - row0) * (long)(col1 - col0)))) return rc;
+    const long kListCap = ctx->list_cap;
 
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
@@ -421,7 +445,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
                                              ctx->d_perm, ctx->stream));
     // Overflow pairs are collected over several launches and finished together: the list kernels
-    // have a fixed latency floor, and kListCap entries cannot be overrun by kListCap / kChunkPairs
+    // have a fixed latency floor, and list_cap entries cannot be overrun by list_cap / kChunkPairs
     // launches even if every pair overflowed.
     auto flush = [&]() -> int {
         PairKernelArgs a;
