@@ -14,17 +14,22 @@
 //   * maxTM's "extend the helix if Tm rises" compares two quotients; it is evaluated in f64 from
 //     the integer state (cross-multiplied, no division) and is decisive unless the two sides
 //     agree to 1e-9.
-//   * a pair that meets an exact tie, a near-tie of Tm, a rejected (H > 0, S > 0) winner or more
-//     cells than the table holds is NOT answered here: it goes to the overflow list and is
-//     finished by the f64 kernels.  Nothing is approximated.
+//   * a pair that meets an exact tie that matters (terminal pick; a cell of the optimal path), a
+//     near-tie of Tm, a rejected (H > 0, S > 0) winner or more cells than the table holds is
+//     NOT answered here: it goes to the hand-over list and is finished by the f64 kernels.
+//     Nothing is approximated.
 //   * each cell records its predecessor; the optimal path is walked by pointer, written to an LDS
 //     scratch [step][thread] and then REPLAYED forwards in f64 with Primer3's own operation order
 //     (pair_core.hpp cand_* = the f64 kernel's formulas), so dS, dH, dG and t carry the same bits
 //     as the CPU oracle.
-// CDNA4 mapping: lane = ordered pair, wave = one row x 64 composition-sorted columns, 512-thread
-// persistent blocks (one per CU, two waves per SIMD, up to 256 VGPRs): 56 slots x {G, W} live in
-// registers behind a switch over the wave-uniform chunk number; LDS holds the 61 KB loop table,
-// the compact f64 / int tables, the predecessor bytes [slot][thread] and the path scratch.
+// CDNA4 mapping: lane = ordered pair, 512-thread persistent blocks (one per CU, two waves per
+// SIMD, up to 256 VGPRs): the slots x {G, W} live in register tuples (static reads, one indexed
+// write per cell); LDS holds the 61 KB loop table, the compact f64 / int tables, the predecessor
+// bytes [slot][thread] and the path scratch.
+//   k_pairs_int       matrix mode: wave = one row x 64 composition-sorted columns, 56 slots; lanes
+//                     whose table is far above their wave's are handed on (lock-step work ~ slots^2)
+//   k_pairs_int_list  list mode: the handed-on pairs without a "needs f64" mark, 64 slots, batches
+//                     counting-sorted by table size in LDS so that a wave's lanes are alike
 #include "pair_core.hpp"
 
 namespace msspe {
