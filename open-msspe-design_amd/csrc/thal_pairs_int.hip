@@ -707,7 +707,7 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
     const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
                        (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
     if (tiles <= 0) return hipSuccess;
-    const int grid = (int)(tiles < 256L * 4 ? tiles : 256L * 4);
+    const int grid = (int)(tiles < 256L ? tiles : 256L);   // one persistent block per CU (152 KB of LDS each)
     hipLaunchKernelGGL(k_pairs_int, dim3(grid), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }
@@ -735,7 +735,7 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
     f.in_count = in_count;
     x.it = it;
     x.reasons = reasons;
-    hipLaunchKernelGGL(k_pairs_int_list, dim3(256 * 2), dim3(kThreadsI), 0, stream, x);
+    hipLaunchKernelGGL(k_pairs_int_list, dim3(256), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }
 
