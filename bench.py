@@ -196,7 +196,8 @@ def main():
             "avg_launch_ms": per_launch_s * 1e3,
             "checks_per_launch": per_launch_checks,
             "executed": executed,
-            "handed_to_f64_stages": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
+            "retried_in_list_mode": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
+            "needed_f64_kernels": stage["needed_f64"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
             "hbm": {"achieved": bytes_per_launch / max(per_launch_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s",
                     "frac": bytes_per_launch / max(per_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBPS,

@@ -111,13 +111,14 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
  * DP did not fit the fast kernel's register-resident table. */
 int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
 
-/* Diagnostics of the exact-integer first stage of the cross-dimer path since the last call
- * (engine-only, no reference counterpart): out[0] = pairs it handed to the f64 kernels because
- * Primer3's double comparisons could go either way, out[1..7] = how many of them met each reason
- * (Tm near-tie, loop == stack/start value with another enthalpy, tie between loops,
- * rejected minimum, tie in the terminal pick, replay mismatch, equal-valued alternative on the
- * optimal path).  Reading resets the counters. */
-int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8]);
+/* Diagnostics of the exact-integer stages of the cross-dimer path since the last call (engine-only,
+ * no reference counterpart).  out[0..7]: the matrix-mode kernel -- out[0] = pairs it did not
+ * answer because Primer3's double comparisons could go either way (they are retried in list
+ * mode), out[1..7] = how many of them met each reason (Tm near-tie, loop == stack/start value with
+ * another enthalpy, tie between loops, rejected minimum, tie in the terminal pick, replay
+ * mismatch, equal-valued alternative on the optimal path).  out[8..15]: the same for the list-mode
+ * kernel; out[8] is the number of pairs that needed the f64 kernels.  Reading resets the counters. */
+int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[16]);
 /* Up to 1024 of those pairs (call before msspe_pair_stage_stats, which resets the sample count):
  * out[i] = row << 40 | col << 16 | reason bits (1 Tm, 2 loop == value, 4 loop tie, 8 rejected
  * minimum, 16 pick tie, 32 replay, 64 alternative on the path). */

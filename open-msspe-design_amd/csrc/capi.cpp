@@ -191,8 +191,8 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
     HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024) * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (9 + 1024) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024 + 8) * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (9 + 1024 + 8) * sizeof(unsigned long long)));
     return MSSPE_OK;
 }
 
@@ -586,15 +586,17 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out)
     return MSSPE_OK;
 }
 
-int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[8])
+int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[16])
 {
     if (!ctx || !out) return MSSPE_ERR_ARG;
-    for (int q = 0; q < 8; ++q) out[q] = 0;
+    for (int q = 0; q < 16; ++q) out[q] = 0;
     if (!ctx->d_reasons) return MSSPE_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out + 8, ctx->d_reasons + 1033, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, 9 * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMemset(ctx->d_reasons + 1033, 0, 8 * sizeof(uint64_t)));
     return MSSPE_OK;
 }
 

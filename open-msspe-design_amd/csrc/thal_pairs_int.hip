@@ -247,7 +247,10 @@ struct IntResult {
 };
 
 // thal ANY for the lane's pair.  n_cells == 0: idle lane.
-template <int NS>
+// RESOLVE: a terminal pick shared by exactly two cells is settled the way Primer3 settles it, by
+// replaying both paths and comparing the two doubles (list mode; in matrix mode such pairs are
+// handed on, because a second walk would be paid by the whole wave).
+template <int NS, bool RESOLVE>
 __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
                                                   unsigned rowmask, int n_cells, int nmax)
 {
@@ -266,8 +269,7 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
     // first slot of the lane's current row and of its two previous non-empty rows: every slot
     // below row_lo2 lies at least three rows above the current cell
     int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
-    int pickG = 0x7fffffff, pickW = 0;
-    bool pickTie = false;
+    int pickG = 0x7fffffff, pickW = 0, pickW2 = 0, nTie = 0;
     unsigned long long softTie = 0ull;   // per lane: slots whose value has an equal-valued alternative
 
     for (int slot_ = 0; slot_ < nmax; ++slot_) {
@@ -356,7 +358,9 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
         {
             const int Gt = G0 + sh.g[b.idxR];
             const bool pick = in & (Gt < pickG);
-            pickTie = pick ? false : (pickTie | (in & (Gt == pickG)));
+            const bool same = in & (Gt == pickG);
+            pickW2 = (same & (nTie == 0)) ? Wcell : pickW2;   // the first later cell with the same value
+            nTie = pick ? 0 : (nTie + (same ? 1 : 0));
             pickG = pick ? Gt : pickG;
             pickW = pick ? Wcell : pickW;
         }
@@ -386,65 +390,106 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
     out.r.conflict = false;
 
     const int nch = (nmax + kC - 1) / kC;
-    defer |= pickTie ? kDeferPick : 0;
+    defer |= (RESOLVE ? nTie > 1 : nTie > 0) ? kDeferPick : 0;
+    const bool second = RESOLVE && !out.r.none && nTie == 1;
+    const bool any_second = RESOLVE && __builtin_amdgcn_ballot_w64(second) != 0ull;   // wave-uniform
 
-    // ---- traceback by pointer: path cells (end first) into the LDS scratch
-    int P = 0;
-    {
-        int cur = pickW & 0xff;
-        bool done = out.r.none;
-        for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
-            const int pc = __builtin_amdgcn_readfirstlane(pc_);
-            int W[kC];
-#pragma unroll
-            for (int e = 0; e < kC; ++e) W[e] = slot_of<NS>(Wa, Wb, Wc, pc * kC + e);
-#pragma unroll
-            for (int e = kC - 1; e >= 0; --e) {
-                const int slot = pc * kC + e;
-                const int pr = sh.pred[slot][threadIdx.x];
-                const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
-                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(core_word(W[e]) & 0x3fff);
-                defer |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
-                P += hit ? 1 : 0;
-                cur = hit ? pr : cur;
-                done = done | (hit & (pr == 0xff));
-            }
+    // ---- walk from the picked cell (and, RESOLVE, from the one that ties with it): traceback by
+    //      pointer into the LDS scratch, then replay forwards in f64 with Primer3's operation order
+    //      (fillMatrix / maxTM), then the terminal dG as thal() compares it
+    double S = 0.0, S_1 = 0.0, Gt_1 = 0.0;
+    int H = 0, P = 0, H_1 = 0, P_1 = 0, dpath = 0, dpath_1 = 0, endW = pickW;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (!any_second) break;
+            S_1 = S;
+            H_1 = H;
+            P_1 = P;
+            dpath_1 = dpath;
+            endW = pickW2;
         }
-    }
-    // ---- replay the path forwards in f64, Primer3's operation order (fillMatrix / maxTM)
-    double S = 0.0;
-    int H = 0, prevW = 0;
-    {
-        const int maxP = wave_max(P);
-        for (int step_ = 0; step_ < maxP; ++step_) {
-            const int step = __builtin_amdgcn_readfirstlane(step_);
-            const int e = P - 1 - step;
-            if (e >= 0) {
-                const int Wstep = sh.path[e & (kPathMax - 1)][threadIdx.x];
-                CellCtx cc;
-                const CellBases b = cell_bases(q, (Wstep >> 4) & 15, Wstep & 15, cc);
-                if (step == 0) {
-                    S = F.S[b.idxL];
-                    H = F.H[b.idxL];
-                } else if (((Wstep & 0xff) - (prevW & 0xff)) == 0x11) {
-                    S = S + F.S[b.wc];
-                    H = H + F.H[b.wc];
-                } else {
-                    const CandGeom g = cand_geometry(cc, prevW);
-                    const CandLoad v = cand_gather(F, g);
-                    S = ((v.sLX + v.sY) + v.sZ) + S;
-                    H = v.hLX + v.hY + H;
+        P = 0;
+        dpath = 0;
+        {
+            int cur = endW & 0xff;
+            bool done = out.r.none | ((pass == 1) & !second);
+            for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
+                const int pc = __builtin_amdgcn_readfirstlane(pc_);
+                int W[kC];
+#pragma unroll
+                for (int e = 0; e < kC; ++e) W[e] = slot_of<NS>(Wa, Wb, Wc, pc * kC + e);
+#pragma unroll
+                for (int e = kC - 1; e >= 0; --e) {
+                    const int slot = pc * kC + e;
+                    const int pr = sh.pred[slot][threadIdx.x];
+                    const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
+                    if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(core_word(W[e]) & 0x3fff);
+                    dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
+                    P += hit ? 1 : 0;
+                    cur = hit ? pr : cur;
+                    done = done | (hit & (pr == 0xff));
                 }
-                prevW = Wstep;
+            }
+        }
+        S = 0.0;
+        H = 0;
+        {
+            int prevW = 0;
+            const int maxP = wave_max(P);
+            for (int step_ = 0; step_ < maxP; ++step_) {
+                const int step = __builtin_amdgcn_readfirstlane(step_);
+                const int e = P - 1 - step;
+                if (e >= 0) {
+                    const int Wstep = sh.path[e & (kPathMax - 1)][threadIdx.x];
+                    CellCtx cc;
+                    const CellBases b = cell_bases(q, (Wstep >> 4) & 15, Wstep & 15, cc);
+                    if (step == 0) {
+                        S = F.S[b.idxL];
+                        H = F.H[b.idxL];
+                    } else if (((Wstep & 0xff) - (prevW & 0xff)) == 0x11) {
+                        S = S + F.S[b.wc];
+                        H = H + F.H[b.wc];
+                    } else {
+                        const CandGeom g = cand_geometry(cc, prevW);
+                        const CandLoad v = cand_gather(F, g);
+                        S = ((v.sLX + v.sY) + v.sZ) + S;
+                        H = v.hLX + v.hY + H;
+                    }
+                    prevW = Wstep;
+                }
+            }
+        }
+        // the replayed enthalpy must be the tracked one; anything else is handed on
+        dpath |= (!out.r.none & (H != (endW >> 16) * 10) & ((pass == 0) | second)) ? kDeferReplay : 0;
+        if (RESOLVE) {
+            // thal.c thal(): the nudged dG the terminal pick compares
+            CellCtx cc;
+            const CellBases b = cell_bases(q, (endW >> 4) & 15, endW & 15, cc);
+            const double rSn = F.S[b.idxR] + kTiny, rHn = (double)F.H[b.idxR] + kTiny;
+            const double Gt = (((double)H + rHn) + K.init_H) - kT37 * ((S + rSn) + K.init_S);
+            if (pass == 0) Gt_1 = Gt;
+            else if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
+                S = S_1;
+                H = H_1;
+                P = P_1;
+                dpath = dpath_1;
+                endW = pickW;
             }
         }
     }
-    // the replayed enthalpy must be the tracked one; anything else is handed on
-    defer |= (!out.r.none & (H != (pickW >> 16) * 10)) ? kDeferReplay : 0;
+    if (RESOLVE && any_second && !second) {   // lanes without a second walk keep their first one
+        S = S_1;
+        H = H_1;
+        P = P_1;
+        dpath = dpath_1;
+        endW = pickW;
+    }
+    defer |= dpath;
     // ---- thal.c drawDimer(): totals
     {
         CellCtx cc;
-        const CellBases b = cell_bases(q, (pickW >> 4) & 15, pickW & 15, cc);
+        const CellBases b = cell_bases(q, (endW >> 4) & 15, endW & 15, cc);
         const double rS = F.S[b.idxR];
         const int rH = F.H[b.idxR];
         const double dH = (double)(H + rH + 200);
@@ -466,7 +511,9 @@ struct IntArgs {
     FastArgs f;
     const IntTables *it;
     unsigned long long *reasons;   // optional statistics: [0] pairs handed on, [1 + b] reason bit b (b < 7),
-                                   // [8] samples kept, [9 ...] samples
+                                   // [8] samples kept, [9 ... 1032] samples; the list mode counts at
+                                   // [1033 ...] (same layout, no samples)
+    int stat_off;                  // 0 (matrix mode) or 1033 (list mode)
 };
 
 // A list entry whose pair needs the f64 kernels (an exact tie was met) carries this bit in .x;
@@ -488,7 +535,7 @@ __device__ __forceinline__ void load_tables_int(SharedI &sh, const IntArgs &a)
 
 // One lock-step DP of the wave: lane = pair (row, col); `take` lanes are computed, `pass_on`
 // lanes go to the output list untouched (flag kept).  same_row: all lanes share `row`.
-template <int NS>
+template <int NS, bool RESOLVE>
 __device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int row, int col, uint64_t pa,
                                            uint64_t pb, bool inside, bool pass_on, unsigned pass_flag,
                                            bool same_row)
@@ -522,7 +569,7 @@ __device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int ro
         }
         return;
     }
-    const IntResult r = run_pair_int<NS>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const IntResult r = run_pair_int<NS, RESOLVE>(sh, a.f.c, q, rowmask, n_cells, nmax);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;
@@ -533,14 +580,14 @@ __device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int ro
     if (a.reasons) {
         const unsigned long long dm = __ballot(deferred);
         if (dm) {   // wave-uniform
-            if (lane == 0) atomicAdd(&a.reasons[0], (unsigned long long)__popcll(dm));
+            if (lane == 0) atomicAdd(&a.reasons[a.stat_off], (unsigned long long)__popcll(dm));
 #pragma unroll
             for (int bit = 0; bit < 7; ++bit) {
                 const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
-                if (lane == 0 && bm) atomicAdd(&a.reasons[1 + bit], (unsigned long long)__popcll(bm));
+                if (lane == 0 && bm) atomicAdd(&a.reasons[a.stat_off + 1 + bit], (unsigned long long)__popcll(bm));
             }
             // a few samples for diagnostics: row << 40 | col << 16 | reasons
-            if (deferred && a.reasons[8] < 1024ull) {
+            if (deferred && a.stat_off == 0 && a.reasons[8] < 1024ull) {
                 const unsigned long long at = atomicAdd(&a.reasons[8], 1ull);
                 if (at < 1024ull)
                     a.reasons[9 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
@@ -589,13 +636,13 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         const uint64_t pa = a.f.pool[row];
         const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
         const int col = (int)a.f.perm[inside ? cq : a.f.col0];
-        wave_pairs<kSlotsMatrix>(sh, a, row, col, pa, pb, inside, false, 0u, true);
+        wave_pairs<kSlotsMatrix, false>(sh, a, row, col, pa, pb, inside, false, 0u, true);
     }
 }
 
-// List mode: the pairs the matrix-mode kernel sent away because of their table size get a second
-// chance in lanes sorted by table size (64 slots); entries flagged kNeedsF64 and what still does
-// not fit pass through to the output list.  Batches of kListBatchI x 512 entries are
+// List mode: the pairs the matrix-mode kernel sent away get a second chance in lanes sorted by
+// table size (64 slots), with the two-cell terminal pick settled by a second walk; what meets
+// another kind of tie or still does not fit goes to the output list.  Batches of kListBatchI x 512 entries are
 // counting-sorted in LDS (the predecessor rows double as scratch) and written back in place.
 constexpr int kListBatchI = 4;
 __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
@@ -619,14 +666,11 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
             const long w = bt * batch + (long)j * kThreadsI + threadIdx.x;
             const bool inside = w < n_work;
             mine[j] = inside ? a.f.in_list[w] : make_uint2(0xffffffffu, 0u);
-            int nc = 255;   // padding sorts last, pass-through entries just before it
+            int nc = 255;   // padding sorts last
             if (inside) {
-                nc = 254;
-                if (!(mine[j].x & kNeedsF64)) {
-                    SeqPair q;
-                    unsigned rowmask;
-                    nc = min(setup_pair(a.f.pool[mine[j].x], a.f.pool[mine[j].y], a.f.k, q, rowmask), 253);
-                }
+                SeqPair q;
+                unsigned rowmask;
+                nc = min(setup_pair(a.f.pool[mine[j].x & ~kNeedsF64], a.f.pool[mine[j].y], a.f.k, q, rowmask), 254);
             }
             key[j] = nc;
             atomicAdd(&hist[nc], 1u);
@@ -667,10 +711,11 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
             const long e = (long)j * kThreadsI + threadIdx.x;
             const bool inside = e < n_own;
             const uint2 pr = own[inside ? e : 0];
-            const bool pass_on = (pr.x & kNeedsF64) != 0u;
+            // marked entries are retried as well: most of them met nothing but a terminal pick
+            // shared by two cells, which this mode settles by walking both
             const int row = (int)(pr.x & ~kNeedsF64), col = (int)pr.y;
-            wave_pairs<kSlotsList>(sh, a, row, col, a.f.pool[inside ? row : 0], a.f.pool[inside ? col : 0], inside,
-                                   pass_on, kNeedsF64, false);
+            wave_pairs<kSlotsList, true>(sh, a, row, col, a.f.pool[inside ? row : 0], a.f.pool[inside ? col : 0], inside,
+                                         false, 0u, false);
         }
         __syncthreads();
     }
@@ -703,6 +748,7 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
     f.in_count = nullptr;
     x.it = it;
     x.reasons = reasons;
+    x.stat_off = 0;
     constexpr int kRowsPerBlock = kThreadsI / 64;
     const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
                        (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
@@ -735,6 +781,7 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
     f.in_count = in_count;
     x.it = it;
     x.reasons = reasons;
+    x.stat_off = 1033;
     hipLaunchKernelGGL(k_pairs_int_list, dim3(256), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }

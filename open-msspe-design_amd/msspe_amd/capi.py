@@ -86,7 +86,7 @@ def load_library() -> C.CDLL:
     L.msspe_cross_dimer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
                                     vp, vp, vp, vp]
     L.msspe_last_overflow_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
-    L.msspe_pair_stage_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.msspe_pair_stage_stats.argtypes = [vp, C.POINTER(C.c_uint64)]   # out[16]
     L.msspe_pair_stage_samples.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
     L.msspe_profile_enable.argtypes = [vp, C.c_int]
     L.msspe_profile_read.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
@@ -239,12 +239,17 @@ class Engine:
         return [(int(x >> 40), int((x >> 16) & 0xffffff), int(x & 0xffff)) for x in v[:n.value]]
 
     def pair_stage_stats(self) -> dict:
-        """Diagnostics of the exact-integer first stage since the last call (resets them)."""
-        v = (C.c_uint64 * 8)()
+        """Diagnostics of the exact-integer stages since the last call (resets them): the
+        matrix-mode kernel's counts at the top level, the list-mode kernel's under "list";
+        "needed_f64" = pairs only the f64 kernels could answer."""
+        v = (C.c_uint64 * 16)()
         self._check(self.L.msspe_pair_stage_stats(self.ptr, v))
         names = ("deferred", "tm_near_tie", "loop_eq_value", "loop_tie", "rejected_min", "pick_tie",
                  "replay_mismatch", "path_tie")
-        return {n: int(v[i]) for i, n in enumerate(names)}
+        out = {n: int(v[i]) for i, n in enumerate(names)}
+        out["list"] = {n: int(v[8 + i]) for i, n in enumerate(names)}
+        out["needed_f64"] = int(v[8])
+        return out
 
     # ---- stage B ---------------------------------------------------------------------------
     def oligo_stats(self, pool, chem: Chem | None = None):

@@ -230,8 +230,11 @@ def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypat
     for key in ("dg", "tm", "bitmap", "row_conflicts"):
         np.testing.assert_array_equal(a[key], b[key])
     n2 = len(pool) ** 2
-    assert 0 < stats["deferred"] < 0.06 * n2
+    assert 0 < stats["deferred"] < 0.06 * n2                  # retried in list mode
+    assert 0 < stats["needed_f64"] < 0.01 * n2                # what only the f64 kernels can answer
+    assert stats["needed_f64"] < stats["deferred"]            # the list mode settles two-cell picks
     assert stats["replay_mismatch"] == 0 and stats["tm_near_tie"] < 0.001 * n2
+    assert stats["list"]["replay_mismatch"] == 0
     samples = eng.pair_stage_samples()
     assert all(0 <= r < len(pool) and 0 <= c < len(pool) and bits for r, c, bits in samples)
     # a few of the pairs that were handed on, against the oracle directly

@@ -45,7 +45,8 @@ def main():
             eng.profile_enable(False)
         print(f"n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
               f"overflow pairs={ovf} ({100.0*ovf/(n*n):.2f} %)", flush=True)
-        print("   integer stage:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats.items()}, flush=True)
+        print("   integer stage:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats.items() if not isinstance(v, dict)},
+              "| list mode:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats["list"].items() if v}, flush=True)
         eng.pair_stage_stats()
 
 
