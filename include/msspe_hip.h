@@ -192,6 +192,26 @@ int msspe_kmer_candidates_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, 
                               const msspe_kmer_opt *opt, int direction,
                               uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out);
 
+/* ---- coverage of the final primer set: replaces the per-segment string search of
+ * coverage_report() (od-msspe/src/main.rs:518-594).  seqs as for msspe_kmer_candidates; fwd_words /
+ * rev_words: packed primers (msspe_pack_oligos) of the two directions, any order;
+ * hit_out[seq * P + partition] (host, n_seq * P bytes, P = (seq_len - segment_size) / overlap_size
+ * + 1) = 1 when the segment's head window holds a forward primer or its tail window holds the
+ * reverse complement of a reverse primer.  Totals per sequence / partition stay on the host. */
+int msspe_segment_coverage(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
+                           const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                           const uint64_t *rev_words, int n_rev, uint8_t *hit_out);
+int msspe_segment_coverage_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, size_t seq_len,
+                               const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                               const uint64_t *rev_words, int n_rev, uint8_t *hit_out);
+
+/* Staging for hosts without a HIP binding (the reference is Rust): copy a host buffer to the
+ * context's device once and use the *_dev entry points on it (the alignment is read by both
+ * directions of stage A and by the coverage report). */
+int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **device_out);
+int msspe_device_free(msspe_ctx *ctx, void *device);
+
+
 /* ---- text rounding at the reference's process boundary ----------- */
 
 float msspe_round_g_f32(double x);                  /* "%g"   -> f32 (od-msspe/src/delta_g.rs:33-35) */

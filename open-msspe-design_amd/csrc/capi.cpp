@@ -858,6 +858,63 @@ int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t
     return rc;
 }
 
+int msspe_segment_coverage_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, size_t seq_len,
+                               const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                               const uint64_t *rev_words, int n_rev, uint8_t *hit_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_seqs || !opt || !hit_out || n_fwd < 0 || n_rev < 0 || (n_fwd && !fwd_words) || (n_rev && !rev_words))
+        return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const int rc = ctx->kmer.coverage(d_seqs, n_seq, seq_len, *opt, fwd_words, n_fwd, rev_words, n_rev,
+                                      hit_out, ctx->stream, err);
+    if (rc) return fail(ctx, rc, err);
+    return MSSPE_OK;
+}
+
+int msspe_segment_coverage(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
+                           const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                           const uint64_t *rev_words, int n_rev, uint8_t *hit_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!seqs || n_seq < 0) return fail(ctx, MSSPE_ERR_ARG, "null sequences");
+    void *d = nullptr;
+    int rc = msspe_device_put(ctx, seqs, (size_t)n_seq * seq_len, &d);
+    if (rc) return rc;
+    rc = msspe_segment_coverage_dev(ctx, (const uint8_t *)d, n_seq, seq_len, opt, fwd_words, n_fwd, rev_words,
+                                    n_rev, hit_out);
+    (void)msspe_device_free(ctx, d);
+    return rc;
+}
+
+int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **device_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!device_out || (bytes && !host)) return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    *device_out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, bytes ? bytes : 1));
+    const hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(ctx, e, "hipMemcpy");
+    }
+    *device_out = d;
+    return MSSPE_OK;
+}
+
+int msspe_device_free(msspe_ctx *ctx, void *device)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!device) return MSSPE_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(device));
+    return MSSPE_OK;
+}
+
 int msspe_host_pair_tables(const char *params_path, const msspe_chem *chem, float dg_threshold,
                            double *fast_S, int32_t *fast_H, int32_t *int_g, int32_t *int_T,
                            double consts[8])

@@ -445,6 +445,53 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
     }
 }
 
+// Coverage of the final primer set (main.rs:518-594): a segment is covered when its head window
+// holds one of the forward primers or its tail window holds the reverse complement of one of the
+// reverse primers.  One wave per segment, lane = window position; the primers are sorted packed
+// words (2 bits per base, base p in bits [2p, 2p+1]) searched by bisection.
+__device__ __forceinline__ bool has_word(const uint64_t *set, int n, uint64_t w)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (set[mid] < w) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && set[lo] == w;
+}
+
+__global__ void __launch_bounds__(256) k_segment_hits(const uint8_t *seqs, size_t seq_len, int n_seg, int P,
+                                                      int seg_size, int stride, int W, int k,
+                                                      const uint64_t *fwd, int n_fwd, const uint64_t *rev,
+                                                      int n_rev, uint8_t *hit)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int per = W - k + 1;
+    for (int seg = wave; seg < n_seg; seg += n_waves) {
+        const size_t base = (size_t)(seg / P) * seq_len + (size_t)(seg % P) * (size_t)stride;
+        bool found = false;
+        for (int p = lane; p < per; p += 64) {
+            uint64_t wf = 0, wr = 0;
+            bool okf = true, okr = true;
+            const uint8_t *head = seqs + base + p;
+            const uint8_t *tail = seqs + base + (size_t)(seg_size - W) + p;
+            for (int q = 0; q < k; ++q) {
+                const int cf = base2(head[q]), cr = base2(tail[k - 1 - q]);
+                okf &= cf >= 0;
+                okr &= cr >= 0;
+                wf |= (uint64_t)(cf & 3) << (2 * q);
+                wr |= (uint64_t)((3 - cr) & 3) << (2 * q);   // reverse complement of the tail word
+            }
+            found |= okf && has_word(fwd, n_fwd, wf);
+            found |= okr && has_word(rev, n_rev, wr);
+        }
+        const unsigned long long any = __ballot(found);
+        if (lane == 0) hit[seg] = any != 0ull;
+    }
+}
+
 uint64_t lex_to_packed(uint64_t lex, int k)
 {
     uint64_t w = 0;
@@ -648,6 +695,43 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
         for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
     }
     *n_out = n_win;
+    return MSSPE_OK;
+}
+
+int KmerStage::coverage(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+                        const uint64_t *fwd_words, int n_fwd, const uint64_t *rev_words, int n_rev,
+                        uint8_t *hit_out, hipStream_t stream, std::string &err)
+{
+    const int k = opt.kmer_size, W = opt.search_window_size;
+    if (k < 1 || k > 31 || W < k || opt.segment_size < W || opt.overlap_size < 1 || n_seq < 0 || n_fwd < 0 ||
+        n_rev < 0) {
+        err = "coverage: unsupported options (need 1 <= k <= 31, k <= window <= segment, stride >= 1)";
+        return k < 1 || k > 31 ? MSSPE_ERR_K : MSSPE_ERR_ARG;
+    }
+    const long P = seq_len < (size_t)opt.segment_size
+                       ? 0
+                       : (long)((seq_len - (size_t)opt.segment_size) / (size_t)opt.overlap_size) + 1;
+    const long n_seg = P * n_seq;
+    if (n_seg == 0) return MSSPE_OK;
+    if (n_seg > 0x7fffffffL) {
+        err = "coverage: alignment too large for 32-bit segment indices";
+        return MSSPE_ERR_ARG;
+    }
+    std::vector<uint64_t> f(fwd_words, fwd_words + n_fwd), r(rev_words, rev_words + n_rev);
+    std::sort(f.begin(), f.end());
+    std::sort(r.begin(), r.end());
+    int rc;
+    if ((rc = ensure(15, sizeof(uint64_t) * (size_t)(n_fwd + n_rev + 2) + (size_t)n_seg, err))) return rc;
+    uint64_t *d_f = (uint64_t *)buf_[15], *d_r = d_f + n_fwd + 1;
+    uint8_t *d_hit = (uint8_t *)(d_r + n_rev + 1);
+    if (n_fwd) KM_TRY(hipMemcpyAsync(d_f, f.data(), sizeof(uint64_t) * n_fwd, hipMemcpyHostToDevice, stream));
+    if (n_rev) KM_TRY(hipMemcpyAsync(d_r, r.data(), sizeof(uint64_t) * n_rev, hipMemcpyHostToDevice, stream));
+    const int grid = (int)std::min<long>(4096, (n_seg + 3) / 4);
+    hipLaunchKernelGGL(k_segment_hits, dim3(grid), dim3(256), 0, stream, d_seqs, seq_len, (int)n_seg, (int)P,
+                       opt.segment_size, opt.overlap_size, W, k, d_f, n_fwd, d_r, n_rev, d_hit);
+    KM_TRY(hipGetLastError());
+    KM_TRY(hipMemcpyAsync(hit_out, d_hit, (size_t)n_seg, hipMemcpyDeviceToHost, stream));
+    KM_TRY(hipStreamSynchronize(stream));   // the sorted host copies must outlive the uploads
     return MSSPE_OK;
 }
 

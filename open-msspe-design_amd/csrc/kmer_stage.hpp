@@ -19,6 +19,12 @@ public:
     int run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
             int direction, uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out,
             hipStream_t stream, std::string &err);
+    // Segment coverage of a primer set (main.rs:518-594): hit_out[seq * P + partition] = 1 when the
+    // segment's head window holds a forward primer or its tail window the reverse complement of a
+    // reverse primer.  fwd_words / rev_words / hit_out: host buffers.
+    int coverage(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+                 const uint64_t *fwd_words, int n_fwd, const uint64_t *rev_words, int n_rev,
+                 uint8_t *hit_out, hipStream_t stream, std::string &err);
     void release();
 
 private:

@@ -110,7 +110,8 @@ int odm_primers_csv(const char *rows_nl, char *out, size_t cap)
     return emit(primers_csv(f, r), out, cap);
 }
 
-// records: "name\tsequence" lines; fwd / rev: selected primer words, one per line
+// records: "name\tsequence" lines; fwd / rev: selected primer words, one per line.  The per-segment
+// search runs on the device (there is no CPU version of it in the product).
 int odm_coverage_report(const char *records_nl, const char *fwd_nl, const char *rev_nl, int segment,
                         int stride, int window, int k, char *out, size_t cap)
 {
@@ -122,7 +123,13 @@ int odm_coverage_report(const char *records_nl, const char *fwd_nl, const char *
     std::vector<KmerStat> f, r;
     for (const auto &w : lines(fwd_nl)) f.push_back({w, SEQ_DIR_FWD, 0, 0, 0, 0, true, 0, 0, 0, false});
     for (const auto &w : lines(rev_nl)) r.push_back({w, SEQ_DIR_REV, 0, 0, 0, 0, true, 0, 0, 0, false});
-    return emit(coverage_report(f, r, recs, segment, stride, window, k), out, cap);
+    try {
+        Engine eng(0, "");
+        return emit(coverage_report(eng, f, r, recs, segment, stride, window, k), out, cap);
+    } catch (const std::exception &e) {
+        emit(e.what(), out, cap);
+        return -2;   // no usable GPU: the text is the reason
+    }
 }
 
 float odm_tm_stat(const float *tm, int n, int population, float *std_out)

@@ -4,6 +4,7 @@
 #include "od_msspe.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -206,36 +207,46 @@ void Engine::fail(int rc) const
 // ---------------------------------------------------------------------------------------------
 // stage A (main.rs:196-235, 331-406)
 // ---------------------------------------------------------------------------------------------
-std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
-                                                 uint8_t direction, const ProgramConfig &cfg,
-                                                 int segment_size, int overlap_size, int window_size)
+DeviceAlignment::DeviceAlignment(Engine &eng, const std::vector<SequenceRecord> &records) : eng_(eng)
 {
-    if (overlap_size < window_size)   // main.rs:201-203
-        throw Panic("Overlap windows size must be greater or equal than search windows size");
-    std::vector<KmerFrequency> out;
-    if (records.empty()) return out;
     // The device path takes one rectangular byte matrix.  Rows shorter than the longest are
     // padded with '-': partition j starts at the same column in every row (main.rs:173-181), pad
     // columns invalidate every k-mer that touches them (main.rs:167), so the extra all-pad
     // partitions of a short row hold no k-mers and can neither be counted nor covered -- the
     // winners are exactly those of the reference's per-record partitioning.
-    size_t L = 0;
-    for (const auto &r : records) L = std::max(L, r.sequence.size());
+    for (const auto &r : records) len_ = std::max(len_, r.sequence.size());
+    rows_ = (int)records.size();
     std::string flat;
-    flat.reserve(L * records.size());
+    flat.reserve(len_ * records.size());
     for (const auto &r : records) {
         flat += r.sequence;
-        flat.append(L - r.sequence.size(), '-');
+        flat.append(len_ - r.sequence.size(), '-');
     }
+    const int rc = msspe_device_put(eng.ctx(), flat.data(), flat.size(), &dev_);
+    if (rc) eng.fail(rc);
+}
+
+DeviceAlignment::~DeviceAlignment()
+{
+    if (dev_) (void)msspe_device_free(eng_.ctx(), dev_);
+}
+
+std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const DeviceAlignment &aln, uint8_t direction,
+                                                 const ProgramConfig &cfg, int segment_size,
+                                                 int overlap_size, int window_size)
+{
+    if (overlap_size < window_size)   // main.rs:201-203
+        throw Panic("Overlap windows size must be greater or equal than search windows size");
+    std::vector<KmerFrequency> out;
+    if (aln.rows() == 0) return out;
     msspe_kmer_opt opt{segment_size, overlap_size, window_size, cfg.primer_config.kmer_size,
                        cfg.max_iterations, cfg.max_mismatch_segments};
     const int cap = std::max(1, cfg.max_iterations);
     std::vector<uint64_t> words((size_t)cap);
     std::vector<uint32_t> freq((size_t)cap);
     int n = 0;
-    const int rc = msspe_kmer_candidates(eng.ctx(), reinterpret_cast<const uint8_t *>(flat.data()),
-                                         (int)records.size(), L, &opt, direction, words.data(),
-                                         freq.data(), cap, &n);
+    const int rc = msspe_kmer_candidates_dev(eng.ctx(), aln.device(), aln.rows(), aln.length(), &opt, direction,
+                                             words.data(), freq.data(), cap, &n);
     if (rc) eng.fail(rc);
     std::vector<char> buf((size_t)opt.kmer_size + 1);
     for (int i = 0; i < n; ++i) {
@@ -243,6 +254,17 @@ std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<
         out.push_back({std::string(buf.data()), direction, freq[(size_t)i]});
     }
     return out;
+}
+
+std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
+                                                 uint8_t direction, const ProgramConfig &cfg,
+                                                 int segment_size, int overlap_size, int window_size)
+{
+    if (overlap_size < window_size)   // main.rs:201-203
+        throw Panic("Overlap windows size must be greater or equal than search windows size");
+    if (records.empty()) return {};
+    const DeviceAlignment aln(eng, records);
+    return find_candidates_kmers(eng, aln, direction, cfg, segment_size, overlap_size, window_size);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,22 +446,6 @@ std::set<std::string> vertex_cover(const std::vector<std::string> &primers, cons
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-std::vector<std::string> window_kmers(const std::string &win, int k)   // main.rs:163-171
-{
-    std::vector<std::string> out;
-    for (size_t p = 0; p + (size_t)k <= win.size(); ++p) {
-        bool ok = true;
-        for (int q = 0; q < k && ok; ++q) {
-            const char c = win[p + (size_t)q];
-            ok = c == 'A' || c == 'T' || c == 'C' || c == 'G' || c == 'U';
-        }
-        if (!ok) continue;
-        std::string w = win.substr(p, (size_t)k);
-        if (std::find(out.begin(), out.end(), w) == out.end()) out.push_back(w);
-    }
-    return out;
-}
-
 std::string fmt(const char *f, double v)
 {
     char b[64];
@@ -447,34 +453,56 @@ std::string fmt(const char *f, double v)
     return b;
 }
 
+std::vector<uint64_t> pack_words(Engine &eng, const std::vector<KmerStat> &list, int k)
+{
+    std::vector<uint64_t> out(list.size());
+    if (list.empty()) return out;
+    std::string flat;
+    for (const auto &p : list) flat += p.word;
+    const int rc = msspe_pack_oligos(flat.data(), (int)list.size(), k, out.data());
+    if (rc) eng.fail(rc);
+    return out;
+}
+
 }  // namespace
 
-std::string coverage_report(const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev,
+std::string coverage_report(Engine &eng, const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev,
                             const std::vector<SequenceRecord> &records, int segment_size,
                             int overlap_size, int window_size, int kmer_size)
 {
-    std::unordered_set<std::string> sel_f, sel_r;
-    for (const auto &p : fwd) sel_f.insert(p.word);
-    for (const auto &p : rev) sel_r.insert(p.word);
+    const DeviceAlignment aln(eng, records);
+    return coverage_report(eng, aln, fwd, rev, records, segment_size, overlap_size, window_size, kmer_size);
+}
+
+std::string coverage_report(Engine &eng, const DeviceAlignment &aln, const std::vector<KmerStat> &fwd,
+                            const std::vector<KmerStat> &rev, const std::vector<SequenceRecord> &records,
+                            int segment_size, int overlap_size, int window_size, int kmer_size)
+{
+    // per-segment search on the device: hit[record * P + partition]
+    const size_t L = aln.length();
+    const size_t P = L < (size_t)segment_size ? 0 : (L - (size_t)segment_size) / (size_t)overlap_size + 1;
+    std::vector<uint8_t> hit(records.size() * P + 1);
+    if (P) {
+        const auto wf = pack_words(eng, fwd, kmer_size), wr = pack_words(eng, rev, kmer_size);
+        msspe_kmer_opt opt{segment_size, overlap_size, window_size, kmer_size, 0, 0};
+        const int rc = msspe_segment_coverage_dev(eng.ctx(), aln.device(), aln.rows(), L, &opt, wf.data(),
+                                                  (int)wf.size(), wr.data(), (int)wr.size(), hit.data());
+        if (rc) eng.fail(rc);
+    }
     size_t total = 0, covered = 0;
     std::map<std::string, std::pair<size_t, size_t>> seq_stats;        // name -> (covered, total)
     std::map<uint16_t, std::pair<size_t, size_t>> partition_stats;
-    for (const auto &r : records) {
+    for (size_t ri = 0; ri < records.size(); ++ri) {
+        const auto &r = records[ri];
         const size_t len = r.sequence.size();
+        auto &se = seq_stats[r.name];
         for (size_t j = 0; (size_t)segment_size <= len && j * (size_t)overlap_size + (size_t)segment_size <= len; ++j) {
-            const std::string part = r.sequence.substr(j * (size_t)overlap_size, (size_t)segment_size);
-            bool hit = false;
-            for (const auto &w : window_kmers(part.substr(0, (size_t)window_size), kmer_size))
-                if (sel_f.count(w)) { hit = true; break; }
-            if (!hit)
-                for (const auto &w : window_kmers(part.substr(part.size() - (size_t)window_size), kmer_size))
-                    if (sel_r.count(reverse_complement(w))) { hit = true; break; }
-            auto &se = seq_stats[r.name];
+            const bool h = hit[ri * P + j] != 0;
             auto &pe = partition_stats[(uint16_t)j];
             se.second += 1;
             pe.second += 1;
             total += 1;
-            if (hit) {
+            if (h) {
                 se.first += 1;
                 pe.first += 1;
                 covered += 1;
@@ -521,8 +549,25 @@ std::string primers_csv(const std::vector<KmerStat> &fwd, const std::vector<Kmer
 // ---------------------------------------------------------------------------------------------
 // main.rs:596-861
 // ---------------------------------------------------------------------------------------------
+namespace {
+// MSSPE_HOST_TIMING=1: wall time of the pipeline phases on stderr (development aid)
+struct PhaseTimer {
+    bool on = std::getenv("MSSPE_HOST_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[od-msspe-hip] %-28s %8.1f ms\n", what,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
+
 int run(const Args &args, std::string &stdout_text)
 {
+    PhaseTimer timer;
     if (args.do_align == "true")
         throw std::runtime_error("--do-align true: MAFFT is a host-side pre-step outside this engine; "
                                  "align the input first and pass --do-align false");
@@ -532,6 +577,7 @@ int run(const Args &args, std::string &stdout_text)
     ss << f.rdbuf();
     const auto records = to_records(ss.str());
     if (records.empty()) throw Panic("No sequences found in the input file");
+    timer.lap("read + to_records");
 
     const int auto_mm = (int)std::min<size_t>(10, std::max<size_t>(1, (records.size() + 49) / 50));
     ProgramConfig cfg;
@@ -549,15 +595,19 @@ int run(const Args &args, std::string &stdout_text)
     cfg.stddev_population = args.stddev_population;
 
     Engine eng(args.device, args.params_path);
-    const auto cand_f = find_candidates_kmers(eng, records, SEQ_DIR_FWD, cfg, args.window_size,
+    const DeviceAlignment aln(eng, records);   // one upload for stage A (both directions) and the report
+    timer.lap("engine + alignment upload");
+    const auto cand_f = find_candidates_kmers(eng, aln, SEQ_DIR_FWD, cfg, args.window_size,
                                               args.overlap_size, args.search_windows_size);
-    const auto cand_r = find_candidates_kmers(eng, records, SEQ_DIR_REV, cfg, args.window_size,
+    const auto cand_r = find_candidates_kmers(eng, aln, SEQ_DIR_REV, cfg, args.window_size,
                                               args.overlap_size, args.search_windows_size);
+    timer.lap("stage A (both directions)");
     const auto stats_f = get_kmer_stats(eng, cand_f, cfg);
     const auto stats_r = get_kmer_stats(eng, cand_r, cfg);
     const auto prim_f = cfg.keep_all ? stats_f : filter_kmers(stats_f, cfg);
     const auto prim_r = cfg.keep_all ? stats_r : filter_kmers(stats_r, cfg);
 
+    timer.lap("stage B + filter");
     std::vector<std::string> primers;
     for (const auto &s : prim_f) primers.push_back(s.word);
     for (const auto &s : prim_r) primers.push_back(s.word);
@@ -571,11 +621,13 @@ int run(const Args &args, std::string &stdout_text)
     for (const auto &p : prim_r)
         if (cfg.keep_all || !deleted.count(p.word)) good_r.push_back(p);
 
-    stdout_text = coverage_report(good_f, good_r, records, args.window_size, args.overlap_size,
+    timer.lap("stage C + vertex cover");
+    stdout_text = coverage_report(eng, aln, good_f, good_r, records, args.window_size, args.overlap_size,
                                   args.search_windows_size, args.kmer_size);
     std::ofstream out(args.output, std::ios::binary);
     if (!out) throw std::runtime_error("cannot write " + args.output);
     out << primers_csv(good_f, good_r);
+    timer.lap("coverage report + csv");
     return 0;
 }
 

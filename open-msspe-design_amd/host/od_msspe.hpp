@@ -120,10 +120,33 @@ private:
     msspe_ctx *ctx_ = nullptr;
 };
 
+// The alignment as the device sees it: one rectangular byte matrix (rows shorter than the longest
+// padded with '-'), copied to the GPU once and read by both directions of stage A and by the
+// coverage report.
+class DeviceAlignment {
+public:
+    DeviceAlignment(Engine &eng, const std::vector<SequenceRecord> &records);
+    ~DeviceAlignment();
+    DeviceAlignment(const DeviceAlignment &) = delete;
+    DeviceAlignment &operator=(const DeviceAlignment &) = delete;
+    const uint8_t *device() const { return static_cast<const uint8_t *>(dev_); }
+    int rows() const { return rows_; }
+    size_t length() const { return len_; }
+
+private:
+    Engine &eng_;
+    void *dev_ = nullptr;
+    int rows_ = 0;
+    size_t len_ = 0;
+};
+
 // main.rs:331-406 (+ :196-255): winners of one direction, in selection order
 std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
                                                  uint8_t direction, const ProgramConfig &cfg,
                                                  int segment_size, int overlap_size, int window_size);
+std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const DeviceAlignment &aln, uint8_t direction,
+                                                 const ProgramConfig &cfg, int segment_size,
+                                                 int overlap_size, int window_size);
 // primer.rs:143-166
 std::vector<PrimerInfo> check_primers(Engine &eng, const std::vector<std::string> &primers);
 // main.rs:408-455, :462-471, :478-490, :492-516
@@ -138,8 +161,12 @@ ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
                          const NtthalOptions &opts, const ProgramConfig &cfg);
 // main.rs:754-798: primers removed by the greedy vertex cover
 std::set<std::string> vertex_cover(const std::vector<std::string> &primers, const ConflictGraph &g);
-// main.rs:518-594 (text goes to `out`)
-std::string coverage_report(const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev,
+// main.rs:518-594 (text goes to `out`): the per-segment search runs on the device
+// (msspe_segment_coverage_dev), the totals per sequence / partition and the text on the host
+std::string coverage_report(Engine &eng, const DeviceAlignment &aln, const std::vector<KmerStat> &fwd,
+                            const std::vector<KmerStat> &rev, const std::vector<SequenceRecord> &records,
+                            int segment_size, int overlap_size, int window_size, int kmer_size);
+std::string coverage_report(Engine &eng, const std::vector<KmerStat> &fwd, const std::vector<KmerStat> &rev,
                             const std::vector<SequenceRecord> &records, int segment_size,
                             int overlap_size, int window_size, int kmer_size);
 // main.rs:834-858

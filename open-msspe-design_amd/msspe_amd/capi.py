@@ -16,7 +16,8 @@ EXPORTS = [
     "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
-    "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
+    "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_segment_coverage", "msspe_segment_coverage_dev",
+    "msspe_device_put", "msspe_device_free", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
     "msspe_round_fixed_f32", "msspe_g_cut",
@@ -95,6 +96,9 @@ def load_library() -> C.CDLL:
     L.msspe_kmer_candidates.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), C.c_int,
                                         vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.msspe_kmer_candidates_dev.argtypes = L.msspe_kmer_candidates.argtypes
+    L.msspe_segment_coverage.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), vp, C.c_int, vp, C.c_int,
+                                         vp]
+    L.msspe_segment_coverage_dev.argtypes = L.msspe_segment_coverage.argtypes
     L.msspe_round_g_f32.restype = C.c_float
     L.msspe_round_g_f32.argtypes = [C.c_double]
     L.msspe_round_fixed_f32.restype = C.c_float
@@ -230,6 +234,19 @@ class Engine:
         v = C.c_uint64()
         self._check(self.L.msspe_last_overflow_pairs(self.ptr, C.byref(v)))
         return int(v.value)
+
+    def segment_coverage(self, seqs: np.ndarray, opt: KmerOpt, fwd: list[str], rev: list[str]) -> np.ndarray:
+        """uint8 (n_seq, P): 1 where the segment is covered by the primer set (main.rs:518-594)."""
+        a = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n_seq, seq_len = a.shape
+        P = 0 if seq_len < opt.segment_size else (seq_len - opt.segment_size) // opt.overlap_size + 1
+        f = pack_oligos(fwd) if len(fwd) else np.zeros(0, dtype=np.uint64)
+        r = pack_oligos(rev) if len(rev) else np.zeros(0, dtype=np.uint64)
+        hit = np.zeros((n_seq, P), dtype=np.uint8)
+        self._check(self.L.msspe_segment_coverage(
+            self.ptr, a.ctypes.data, n_seq, seq_len, C.byref(opt), f.ctypes.data, len(f), r.ctypes.data, len(r),
+            hit.ctypes.data))
+        return hit
 
     def pair_stage_samples(self):
         """[(row, col, reason bits)] for up to 1024 pairs the integer stage handed on."""

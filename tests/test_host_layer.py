@@ -103,16 +103,34 @@ def test_csv_and_coverage_report_text(host, oracle):
                    "F,Primer_0_F,AGCCCGTGTAAAC,0.54,43.25,2.12,43.73\n"
                    "F,Primer_1_F,GGGCCGTGTAAAC,0.62,43.25,2.12,47.00\n"
                    "R,Primer_0_R,TTTCCGTGTAAAC,0.38,40.00,1.00,39.99\n")   # f32(39.995) = 39.99499...
+
+
+@pytest.mark.gpu
+def test_coverage_report_text(host, oracle):
+    """main.rs:518-594: the per-segment search runs on the device (msspe_segment_coverage_dev), the
+    totals and the text on the host; ragged record lengths and gap runs included."""
     import msspe_amd
+    import ref_pipeline
     g = msspe_amd.synth.aligned_genomes(6, 1400)
     recs = [(f"s{i}", bytes(r).decode()) for i, r in enumerate(g)]
-    segs = oracle.Segments([s for _, s in recs], 500, 250, 50, 13)
+    recs[2] = (recs[2][0], recs[2][1][:1130])            # a shorter record: fewer partitions
+    recs[4] = (recs[4][0], recs[4][1][:700] + "-" * 40 + recs[4][1][740:])
+    segs = oracle.Segments([s for _, s in recs[:2]], 500, 250, 50, 13)
     fwd = [w for w, _ in segs.candidates(0, 3, 1)]
     rev = [w for w, _ in segs.candidates(1, 2, 1)]
-    want = ref_pipeline.coverage_report(fwd, rev, recs, 500, 250, 50, 13)
-    rc, out = call(host.odm_coverage_report, "\n".join(f"{n}\t{s}" for n, s in recs).encode(),
-                   "\n".join(fwd).encode(), "\n".join(rev).encode(), 500, 250, 50, 13)
-    assert out == want
+    for f, r in ((fwd, rev), (fwd, []), ([], rev)):
+        want = ref_pipeline.coverage_report(f, r, recs, 500, 250, 50, 13)
+        rc, out = call(host.odm_coverage_report, "\n".join(f"{n}\t{s}" for n, s in recs).encode(),
+                       "\n".join(f).encode(), "\n".join(r).encode(), 500, 250, 50, 13)
+        assert rc > 0 and out == want
+
+
+def test_coverage_report_needs_a_gpu(host):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rc, out = call(host.odm_coverage_report, b"a\tACGT", b"ACGT", b"", 4, 2, 4, 2)
+    assert rc == -2 and out
 
 
 def test_cli_needs_a_gpu_for_the_pipeline(host, tmp_path):
