@@ -4,6 +4,7 @@
 #include "od_msspe.hpp"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -147,25 +148,35 @@ Args Args::parse(int argc, const char *const *argv)
 // ---------------------------------------------------------------------------------------------
 std::vector<SequenceRecord> to_records(const std::string &fasta)
 {
-    std::vector<SequenceRecord> out;
-    std::istringstream in(fasta);
-    std::string line;
-    bool have = false;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (!line.empty() && line[0] == '>') {
-            SequenceRecord r;
-            const size_t sp = line.find(' ');
-            r.name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-            out.push_back(r);
-            have = true;
-        } else if (have) {
-            for (char c : line) {
-                char u = (char)std::toupper((unsigned char)c);
-                if (u == 'U') u = 'T';
-                out.back().sequence.push_back(u);
-            }
+    // one pass over the buffer; sequence bytes go through a 256-entry table (upper case, U -> T)
+    static const auto table = [] {
+        std::array<char, 256> t{};
+        for (int c = 0; c < 256; ++c) {
+            char u = (char)std::toupper(c);
+            t[(size_t)c] = u == 'U' ? 'T' : u;
         }
+        return t;
+    }();
+    std::vector<SequenceRecord> out;
+    const char *p = fasta.data(), *end = p + fasta.size();
+    size_t reserve_hint = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
+        const char *stop = nl ? nl : end;
+        const char *last = stop;
+        if (last > p && last[-1] == '\r') --last;
+        if (last > p && *p == '>') {
+            if (!out.empty()) reserve_hint = std::max(reserve_hint, out.back().sequence.size());
+            const char *sp = static_cast<const char *>(std::memchr(p, ' ', (size_t)(last - p)));
+            out.push_back({std::string(p + 1, sp ? sp : last), std::string()});
+            out.back().sequence.reserve(reserve_hint);
+        } else if (!out.empty()) {
+            std::string &seq = out.back().sequence;
+            const size_t at = seq.size();
+            seq.resize(at + (size_t)(last - p));
+            for (size_t q = 0; q < (size_t)(last - p); ++q) seq[at + q] = table[(unsigned char)p[q]];
+        }
+        p = nl ? nl + 1 : end;
     }
     return out;
 }
@@ -571,11 +582,18 @@ int run(const Args &args, std::string &stdout_text)
     if (args.do_align == "true")
         throw std::runtime_error("--do-align true: MAFFT is a host-side pre-step outside this engine; "
                                  "align the input first and pass --do-align false");
-    std::ifstream f(args.input, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot read " + args.input);
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const auto records = to_records(ss.str());
+    std::string fasta;
+    {
+        std::ifstream f(args.input, std::ios::binary | std::ios::ate);
+        if (!f) throw std::runtime_error("cannot read " + args.input);
+        const std::streamoff size = f.tellg();
+        f.seekg(0);
+        fasta.resize((size_t)std::max<std::streamoff>(size, 0));
+        if (size > 0) f.read(&fasta[0], size);
+        if (!f) throw std::runtime_error("cannot read " + args.input);
+    }
+    const auto records = to_records(fasta);
+    std::string().swap(fasta);
     if (records.empty()) throw Panic("No sequences found in the input file");
     timer.lap("read + to_records");
 
