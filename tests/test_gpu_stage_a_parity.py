@@ -112,3 +112,26 @@ def test_edge_inputs(eng, m, oracle):
     assert eng.kmer_candidates(gaps, opt, 1)[0] == []
     with pytest.raises(m.MsspeError):                                               # stride < window
         eng.kmer_candidates(gaps, m.KmerOpt(500, 40, 50, 13, 10, 1), 0)
+
+
+def test_segment_coverage_matches_a_string_search(eng, m, oracle):
+    """msspe_segment_coverage vs. the reference's rule (main.rs:518-594): head window holds a
+    forward primer, or the tail window holds the reverse complement of a reverse primer."""
+    genomes = m.synth.aligned_genomes(30, 5000)
+    seqs = [bytes(r).decode() for r in genomes]
+    segs = oracle.Segments(seqs, 500, 250, 50, 13)
+    fwd = [w for w, _ in segs.candidates(0, 12, 1)]
+    rev = [w for w, _ in segs.candidates(1, 9, 1)]
+    opt = m.KmerOpt(500, 250, 50, 13, 0, 0)
+    for f, r in ((fwd, rev), (fwd, []), ([], rev), ([], [])):
+        hit = eng.segment_coverage(genomes, opt, f, r)
+        want = np.zeros_like(hit)
+        sf, sr = set(f), set(r)
+        for i, s in enumerate(seqs):
+            for j in range(hit.shape[1]):
+                part = s[j * 250: j * 250 + 500]
+                head = oracle.find_kmers(part[:50], 13)
+                tail = oracle.find_kmers(part[-50:], 13)
+                want[i, j] = any(w in sf for w in head) or any(oracle.reverse_complement(w) in sr for w in tail)
+        np.testing.assert_array_equal(hit, want)
+    assert hit.shape == (30, (5000 - 500) // 250 + 1)
