@@ -130,7 +130,7 @@ __device__ __forceinline__ Visit visit_geometry(const ICell &c, int Wp)
     v.geo = (jj <= c.jm1p) & (d >= 0);
     v.stack = (Wp & 0xff) == c.cstk;         // the cell (i-1, j-1)
     const int po4 = (Wp >> 8) & 0xff;        // po << 2 (bits 8, 9 of W are zero)
-    const bool bulge = (d < 16) | ((d & 15) == 0);
+    const bool bulge = (d < 16) | (jj == c.jm1p);   // l1 == 0 or l2 == 0 (for a valid geometry)
     const int pe4 = bulge ? ((po4 & 12) | c.a16) : po4;
     // a valid geometry has 0 <= d <= 238 and pe4 < 256: in range.  Everything else reads T[0], the
     // stacked-pair row, which holds kBig: no clamp and no separate validity mask in the compares.
@@ -149,7 +149,7 @@ __device__ __forceinline__ Visit visit_geometry_far(const ICell &c, int Wp)
     v.geo = jj <= c.jm1p;
     v.stack = false;
     const int po4 = (Wp >> 8) & 0xff;
-    const bool bulge = (d & 15) == 0;
+    const bool bulge = jj == c.jm1p;   // l2 == 0
     const int pe4 = bulge ? ((po4 & 12) | c.a16) : po4;
     v.idx4 = v.geo ? ((d << 8) | pe4) : 0;
     v.y = bulge ? 0 : c.yTS;
