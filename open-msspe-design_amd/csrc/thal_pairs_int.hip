@@ -37,9 +37,13 @@ namespace msspe {
 namespace {
 
 constexpr int kC = 4;              // slots per chunk (= predecessor evaluations in flight)
-constexpr int kSlotsMatrix = 56;   // table of the matrix-mode kernel (the largest tables drag their waves)
+// Two shapes of the matrix-mode kernel.  Oligos up to 13 bases need 189 rows of the loop table,
+// which leaves LDS for a 768-thread block: with 48 slots the kernel fits 168 VGPRs, i.e. THREE
+// waves per SIMD (the scan is VALU-bound, the rest of a cell latency-bound: the third wave fills
+// the gaps); pairs with more cells (11 %) go to the list mode.  Longer oligos: 512 threads, 56 slots.
+constexpr int kSlotsSmall = 48, kThreadsSmall = 768, kRowsSmall = 11 * 17 + 2;   // k <= 13
+constexpr int kSlotsMatrix = 56;   // k <= 16 (the largest tables drag their waves)
 constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
-constexpr int kSlotsMax = 64;      // register tuples and LDS rows are sized for this
 constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
 constexpr int kDragCost = 16;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
@@ -64,6 +68,11 @@ struct TabTypes<56> {
     typedef v8i C;
 };
 template <>
+struct TabTypes<48> {
+    typedef v16i B;
+    typedef v8i C;   // unused
+};
+template <>
 struct TabTypes<64> {
     typedef v32i B;
     typedef v8i C;   // unused
@@ -78,16 +87,19 @@ __device__ __forceinline__ int slot_of(const v32i a, const typename TabTypes<NS>
                                        const typename TabTypes<NS>::C c, int x)
 {
     if constexpr (NS == 56) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
+    else if constexpr (NS == 48) return x < 32 ? a[x & 31] : b[(x - 32) & 15];
     else return x < 32 ? a[x & 31] : b[(x - 32) & 31];
 }
 
+template <int NS, int THREADS, int TROWS>
 struct SharedI {
-    int T[IntTables::kRows * 64];
+    static constexpr int kThreads = THREADS, kRows = TROWS;
+    int T[TROWS * 64];
     Lds F;                              // f64 S + int H (replay, end terms)
     int g[FastTables::kCount];
     double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
-    unsigned char pred[kSlotsMax][kThreadsI];
-    unsigned short path[kPathMax][kThreadsI];
+    unsigned char pred[NS][THREADS];
+    unsigned short path[kPathMax][THREADS];
 };
 
 struct ICell {
@@ -250,8 +262,8 @@ struct IntResult {
 // RESOLVE: a terminal pick shared by exactly two cells is settled the way Primer3 settles it, by
 // replaying both paths and comparing the two doubles (list mode; in matrix mode such pairs are
 // handed on, because a second walk would be paid by the whole wave).
-template <int NS, bool RESOLVE>
-__device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts &K, const SeqPair &q,
+template <int NS, bool RESOLVE, class SH>
+__device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, const SeqPair &q,
                                                   unsigned rowmask, int n_cells, int nmax)
 {
     const Lds &F = sh.F;
@@ -376,6 +388,9 @@ __device__ __forceinline__ IntResult run_pair_int(SharedI &sh, const ThalConsts 
                 Gc[(slot - 48) & 7] = G0;
                 Wc[(slot - 48) & 7] = Wcell;
             }
+        } else if constexpr (NS == 48) {
+            Gb[(slot - 32) & 15] = G0;
+            Wb[(slot - 32) & 15] = Wcell;
         } else {
             Gb[(slot - 32) & 31] = G0;
             Wb[(slot - 32) & 31] = Wcell;
@@ -520,9 +535,11 @@ struct IntArgs {
 // entries without it only left their wave because of their table size and may be retried here.
 constexpr unsigned kNeedsF64 = 0x80000000u;
 
-__device__ __forceinline__ void load_tables_int(SharedI &sh, const IntArgs &a)
+template <class SH>
+__device__ __forceinline__ void load_tables_int(SH &sh, const IntArgs &a)
 {
-    for (int e = threadIdx.x; e < IntTables::kRows * 64; e += kThreadsI) sh.T[e] = a.it->T[e];
+    constexpr int kThreadsI = SH::kThreads;
+    for (int e = threadIdx.x; e < SH::kRows * 64; e += kThreadsI) sh.T[e] = a.it->T[e];
     for (int e = threadIdx.x; e < FastTables::kCount; e += kThreadsI) {
         sh.F.S[e] = a.f.ft->S[e];
         sh.F.H[e] = a.f.ft->H[e];
@@ -535,8 +552,8 @@ __device__ __forceinline__ void load_tables_int(SharedI &sh, const IntArgs &a)
 
 // One lock-step DP of the wave: lane = pair (row, col); `take` lanes are computed, `pass_on`
 // lanes go to the output list untouched (flag kept).  same_row: all lanes share `row`.
-template <int NS, bool RESOLVE>
-__device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int row, int col, uint64_t pa,
+template <int NS, bool RESOLVE, class SH>
+__device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, int col, uint64_t pa,
                                            uint64_t pb, bool inside, bool pass_on, unsigned pass_flag,
                                            bool same_row)
 {
@@ -569,7 +586,7 @@ __device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int ro
         }
         return;
     }
-    const IntResult r = run_pair_int<NS, RESOLVE>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const IntResult r = run_pair_int<NS, RESOLVE, SH>(sh, a.f.c, q, rowmask, n_cells, nmax);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;
@@ -618,12 +635,14 @@ __device__ __forceinline__ void wave_pairs(SharedI &sh, const IntArgs &a, int ro
 }
 
 // Matrix mode: wave = one row x 64 consecutive entries of the composition-sorted column list.
-__global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
+template <int NS, int THREADS, int TROWS>
+__global__ void __launch_bounds__(THREADS) k_pairs_int(IntArgs a)
 {
-    __shared__ SharedI sh;
+    typedef SharedI<NS, THREADS, TROWS> SH;
+    __shared__ SH sh;
     load_tables_int(sh, a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kRowsPerBlock = kThreadsI / 64;
+    constexpr int kRowsPerBlock = THREADS / 64;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
     const int nrowg = (a.f.row1 - a.f.row0 + kRowsPerBlock - 1) / kRowsPerBlock;
     const long tiles = (long)ncolg * nrowg;
@@ -636,7 +655,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
         const uint64_t pa = a.f.pool[row];
         const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
         const int col = (int)a.f.perm[inside ? cq : a.f.col0];
-        wave_pairs<kSlotsMatrix, false>(sh, a, row, col, pa, pb, inside, false, 0u, true);
+        wave_pairs<NS, false, SH>(sh, a, row, col, pa, pb, inside, false, 0u, true);
     }
 }
 
@@ -647,7 +666,8 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int(IntArgs a)
 constexpr int kListBatchI = 4;
 __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
 {
-    __shared__ SharedI sh;
+    typedef SharedI<kSlotsList, kThreadsI, IntTables::kRows> SH;
+    __shared__ SH sh;
     load_tables_int(sh, a);
     static_assert(sizeof(sh.pred) >= sizeof(uint2) * kListBatchI * kThreadsI + sizeof(unsigned) * 256,
                   "the predecessor rows must hold one sorted batch");
@@ -714,7 +734,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
             // marked entries are retried as well: most of them met nothing but a terminal pick
             // shared by two cells, which this mode settles by walking both
             const int row = (int)(pr.x & ~kNeedsF64), col = (int)pr.y;
-            wave_pairs<kSlotsList, true>(sh, a, row, col, a.f.pool[inside ? row : 0], a.f.pool[inside ? col : 0], inside,
+            wave_pairs<kSlotsList, true, SH>(sh, a, row, col, a.f.pool[inside ? row : 0], a.f.pool[inside ? col : 0], inside,
                                          false, 0u, false);
         }
         __syncthreads();
@@ -724,6 +744,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
 }  // namespace
 
 int pairs_int_slots() { return kSlotsMatrix; }
+int pairs_int_slots_small() { return kSlotsSmall; }
 
 hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
                             hipStream_t stream)
@@ -749,12 +770,24 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
     x.it = it;
     x.reasons = reasons;
     x.stat_off = 0;
-    constexpr int kRowsPerBlock = kThreadsI / 64;
-    const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
-                       (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
-    if (tiles <= 0) return hipSuccess;
-    const int grid = (int)(tiles < 256L ? tiles : 256L);   // one persistent block per CU (152 KB of LDS each)
-    hipLaunchKernelGGL(k_pairs_int, dim3(grid), dim3(kThreadsI), 0, stream, x);
+    // one persistent block per CU (about 150 KB of LDS each)
+    if (a.k <= 13) {
+        constexpr int kRowsPerBlock = kThreadsSmall / 64;
+        const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
+                           (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
+        if (tiles <= 0) return hipSuccess;
+        const int grid = (int)(tiles < 256L ? tiles : 256L);
+        hipLaunchKernelGGL((k_pairs_int<kSlotsSmall, kThreadsSmall, kRowsSmall>), dim3(grid), dim3(kThreadsSmall), 0,
+                           stream, x);
+    } else {
+        constexpr int kRowsPerBlock = kThreadsI / 64;
+        const long tiles = (long)((a.col1 - a.col0 + 63) / 64) *
+                           (long)((a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock);
+        if (tiles <= 0) return hipSuccess;
+        const int grid = (int)(tiles < 256L ? tiles : 256L);
+        hipLaunchKernelGGL((k_pairs_int<kSlotsMatrix, kThreadsI, IntTables::kRows>), dim3(grid), dim3(kThreadsI), 0,
+                           stream, x);
+    }
     return hipGetLastError();
 }
 
