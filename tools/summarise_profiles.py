@@ -13,6 +13,7 @@ RAW = ROOT / "gpurun_out" / "profiles_raw"
 OUT = ROOT / "profiles"
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 KERNEL = "k_pairs_int"
+KERNEL_MATCH = "k_pairs_int<"   # the matrix-mode instantiation (the list mode is k_pairs_int_list)
 
 
 def pmc(sub):
@@ -20,7 +21,7 @@ def pmc(sub):
     dur = []
     for f in glob.glob(str(RAW / sub / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if KERNEL not in r["Kernel_Name"]:
+            if KERNEL_MATCH not in r["Kernel_Name"]:
                 continue
             tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -41,6 +42,7 @@ checks = 67108864.0   # one launch of the 16,384-primer probe: 4,096 rows x 16,3
 waves = checks / 64.0
 clock_ghz = c2["GRBM_GUI_ACTIVE"] / 8.0 / (ms2 * 1e-3) / 1e9
 simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
+wave_slots = 1024.0 * 3.0   # 768-thread blocks: three waves per SIMD
 with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 tools/perf_probe.py 16384 ; kernel {KERNEL},\n"
             f"# mean per dispatch (2^26 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
