@@ -22,12 +22,13 @@
 //     scratch [step][thread] and then REPLAYED forwards in f64 with Primer3's own operation order
 //     (pair_core.hpp cand_* = the f64 kernel's formulas), so dS, dH, dG and t carry the same bits
 //     as the CPU oracle.
-// CDNA4 mapping: lane = ordered pair, 512-thread persistent blocks (one per CU, two waves per
-// SIMD, up to 256 VGPRs): the slots x {G, W} live in register tuples (static reads, one indexed
-// write per cell); LDS holds the 61 KB loop table, the compact f64 / int tables, the predecessor
-// bytes [slot][thread] and the path scratch.
-//   k_pairs_int       matrix mode: wave = one row x 64 composition-sorted columns, 56 slots; lanes
-//                     whose table is far above their wave's are handed on (lock-step work ~ slots^2)
+// CDNA4 mapping: lane = ordered pair, persistent blocks (one per CU): the slots x {G, W} live in
+// register tuples (static reads, one indexed write per cell); LDS holds the loop table (48 / 61
+// KB), the compact f64 / int tables, the predecessor bytes [slot][thread] and the path scratch.
+//   k_pairs_int       matrix mode: wave = one row x 64 composition-sorted columns.  k <= 13: 768
+//                     threads, 48 slots, 168 VGPRs = three waves per SIMD; else 512 threads, 56
+//                     slots.  Lanes whose table is too large, or far above their wave's, are
+//                     handed on (lock-step work ~ slots^2)
 //   k_pairs_int_list  list mode: the handed-on pairs without a "needs f64" mark, 64 slots, batches
 //                     counting-sorted by table size in LDS so that a wave's lanes are alike
 #include "pair_core.hpp"
