@@ -42,7 +42,7 @@ constexpr int kC = 4;              // slots per chunk (= predecessor evaluations
 // which leaves LDS for a 768-thread block: with 48 slots the kernel fits 168 VGPRs, i.e. THREE
 // waves per SIMD (the scan is VALU-bound, the rest of a cell latency-bound: the third wave fills
 // the gaps); pairs with more cells (11 %) go to the list mode.  Longer oligos: 512 threads, 56 slots.
-constexpr int kSlotsSmall = 48, kThreadsSmall = 768, kRowsSmall = 11 * 17 + 2;   // k <= 13
+constexpr int kSlotsSmall = 52, kThreadsSmall = 768, kRowsSmall = 11 * 17 + 2;   // k <= 13
 constexpr int kSlotsMatrix = 56;   // k <= 16 (the largest tables drag their waves)
 constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
 constexpr int kThreadsI = 512;
@@ -73,6 +73,12 @@ struct TabTypes<48> {
     typedef v16i B;
     typedef v8i C;   // unused
 };
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <>
+struct TabTypes<52> {
+    typedef v16i B;
+    typedef v4i C;
+};
 template <>
 struct TabTypes<64> {
     typedef v32i B;
@@ -89,6 +95,7 @@ __device__ __forceinline__ int slot_of(const v32i a, const typename TabTypes<NS>
 {
     if constexpr (NS == 56) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
     else if constexpr (NS == 48) return x < 32 ? a[x & 31] : b[(x - 32) & 15];
+    else if constexpr (NS == 52) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 3]);
     else return x < 32 ? a[x & 31] : b[(x - 32) & 31];
 }
 
@@ -392,6 +399,14 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         } else if constexpr (NS == 48) {
             Gb[(slot - 32) & 15] = G0;
             Wb[(slot - 32) & 15] = Wcell;
+        } else if constexpr (NS == 52) {
+            if (slot < 48) {
+                Gb[(slot - 32) & 15] = G0;
+                Wb[(slot - 32) & 15] = Wcell;
+            } else {
+                Gc[(slot - 48) & 3] = G0;
+                Wc[(slot - 48) & 3] = Wcell;
+            }
         } else {
             Gb[(slot - 32) & 31] = G0;
             Wb[(slot - 32) & 31] = Wcell;
