@@ -47,7 +47,7 @@ constexpr int kSlotsMatrix = 56;   // k <= 16 (the largest tables drag their wav
 constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
 constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
-constexpr int kDragCost = 16;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
+constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
 constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
 
 // slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
