@@ -41,7 +41,7 @@ struct ChemEntry {
 
 constexpr long kChunkPairs = 1L << 26;       // pairs per launch of the all-pairs kernel (the tail of a launch costs 2.4 % at 2^24)
 constexpr long kListCapMin = 1L << 26;       // hand-over list entries: one launch can never overrun it
-constexpr long kListCapMax = 1L << 29;       // 4 GB per list: 32 launches between flushes (288 GB HBM)
+constexpr long kListCapMax = 1L << 30;       // 8 GB per list: 16 launches between flushes (288 GB HBM)
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace
@@ -169,7 +169,7 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
     while (want < total_pairs && want < kListCapMax) want <<= 1;
     if (const char *e = std::getenv("MSSPE_LIST_CAP_LOG2")) {   // testing aid: force flushes mid-screen
         const long lg = std::strtol(e, nullptr, 10);
-        if (lg >= 26 && lg <= 29) want = 1L << lg;
+        if (lg >= 26 && lg <= 30) want = 1L << lg;
     }
     if (ctx->ovf_list && (ctx->list_cap == want || (ctx->list_cap > want && !std::getenv("MSSPE_LIST_CAP_LOG2"))))
         return MSSPE_OK;
@@ -423,6 +423,9 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     g.wsH = ctx->wsH;
     g.ws_lanes = kGenericLanes;
     long rows_per_chunk = kChunkPairs / ncols;
+    // whole row groups of the first-stage kernels (12 or 8 waves per block): no idle waves in the
+    // last tile row of a launch
+    if (rows_per_chunk > 24) rows_per_chunk -= rows_per_chunk % 24;
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (!fast) {
         // generic kernel over the whole block, a band of rows per launch (matrix mode derives
