@@ -155,7 +155,7 @@ def main():
 
     if rank == 0:
         conflicts = int(d_conf.sum().item())
-        # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^26 checks of this rank's block
+        # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^27 checks of this rank's block
         checks_rank = float(shard) * float(n) * args.steps
         per_launch_checks = checks_rank / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)

@@ -39,8 +39,8 @@ struct ChemEntry {
     bool int_ok = false;
 };
 
-constexpr long kChunkPairs = 1L << 26;       // pairs per launch of the all-pairs kernel (the tail of a launch costs 2.4 % at 2^24)
-constexpr long kListCapMin = 1L << 26;       // hand-over list entries: one launch can never overrun it
+constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
+constexpr long kListCapMin = 1L << 27;       // hand-over list entries: one launch can never overrun it
 constexpr long kListCapMax = 1L << 30;       // 8 GB per list: 16 launches between flushes (288 GB HBM)
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
@@ -169,7 +169,7 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
     while (want < total_pairs && want < kListCapMax) want <<= 1;
     if (const char *e = std::getenv("MSSPE_LIST_CAP_LOG2")) {   // testing aid: force flushes mid-screen
         const long lg = std::strtol(e, nullptr, 10);
-        if (lg >= 26 && lg <= 30) want = 1L << lg;
+        if (lg >= 27 && lg <= 30) want = 1L << lg;
     }
     if (ctx->ovf_list && (ctx->list_cap == want || (ctx->list_cap > want && !std::getenv("MSSPE_LIST_CAP_LOG2"))))
         return MSSPE_OK;

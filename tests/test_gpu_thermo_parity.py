@@ -176,11 +176,11 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables):
 
 
 def test_large_pool_properties(eng, m, oracle, oracle_tables, monkeypatch):
-    """16,384^2 = 2.7e8 ordered pairs (16 launches; the hand-over lists are forced down to 2^26
-    entries so that the stages behind the first one run four times mid-screen): size-independent
+    """16,384^2 = 2.7e8 ordered pairs (16 launches; the hand-over lists are forced down to 2^27
+    entries so that the stages behind the first one run twice mid-screen): size-independent
     properties of the counts/bitmap outputs plus an oracle check of sampled rows."""
     import torch
-    monkeypatch.setenv("MSSPE_LIST_CAP_LOG2", "26")
+    monkeypatch.setenv("MSSPE_LIST_CAP_LOG2", "27")
     n = 16384
     pool_ascii = m.synth.random_pool(n, 13)
     d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()

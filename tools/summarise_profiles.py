@@ -38,14 +38,14 @@ c1, ms1, n1 = pmc("pmc1")
 c2, ms2, n2 = pmc("pmc2")
 cf, msf, nf = pmc("pmc_fetch")
 cw, msw, nw = pmc("pmc_write")
-checks = 67108864.0   # one launch of the 16,384-primer probe: 4,096 rows x 16,384 columns
+checks = 134217728.0   # one launch of the 16,384-primer probe: 8,184 rows x 16,384 columns (approximately 2^27)
 waves = checks / 64.0
 clock_ghz = c2["GRBM_GUI_ACTIVE"] / 8.0 / (ms2 * 1e-3) / 1e9
 simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
 wave_slots = 1024.0 * 3.0   # 768-thread blocks: three waves per SIMD
 with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 tools/perf_probe.py 16384 ; kernel {KERNEL},\n"
-            f"# mean per dispatch (2^26 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
+            f"# mean per dispatch (2^27 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
             f"# GRBM_GUI_ACTIVE sums the 8 XCDs (/8 = {c2['GRBM_GUI_ACTIVE']/8e6:.1f} M cycles in {ms2:.2f} ms = {clock_ghz:.2f} GHz)\n")
     for name, (c, ms, n) in (("pass 1", (c1, ms1, n1)), ("pass 2", (c2, ms2, n2)), ("FETCH_SIZE [KB]", (cf, msf, nf)),
                              ("WRITE_SIZE [KB]", (cw, msw, nw))):
@@ -65,7 +65,7 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
-    "note": "each launch covers 2^26 ordered pairs; traffic = table loads of the 1,024 persistent blocks (148 KB each, mostly L2 hits), "
+    "note": "each launch covers 2^27 ordered pairs; traffic = table loads of the 1,024 persistent blocks (148 KB each, mostly L2 hits), "
             "the 64-byte atomics that set conflict bits (0.5 % of pairs) and the list of pairs handed to the later stages (about 5 %, 8 B each); "
             "algorithmic bytes per launch are about 10 MB"}, indent=1))
 (OUT / "pmc_latest.json").write_text(json.dumps({
