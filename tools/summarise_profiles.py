@@ -12,6 +12,8 @@ ROOT = Path(__file__).resolve().parent.parent
 RAW = ROOT / "gpurun_out" / "profiles_raw"
 OUT = ROOT / "profiles"
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+kLaunchChecks = 134217728.0            # 2^27 pairs: one full launch
+kProbeChecks = 3.0 * 16384.0 * 16384.0   # tools/perf_probe.py 16384 = three passes over the pool
 KERNEL = "k_pairs_int"
 KERNEL_MATCH = "k_pairs_int<"   # the matrix-mode instantiation (the list mode is k_pairs_int_list)
 
@@ -25,8 +27,12 @@ def pmc(sub):
                 continue
             tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    return ({k: sum(v) / len(v) for k, v in tot.items()}, (sum(dur) / len(dur) if dur else 0.0),
-            len(dur) // max(len(tot), 1))
+    n = len(dur) // max(len(tot), 1)
+    # the probe's launches are not all the same size (the last one of a pass is small): report the
+    # mean of one FULL-SIZE-EQUIVALENT launch = totals scaled to kLaunchChecks checks
+    scale = kLaunchChecks / (kProbeChecks / max(n, 1))
+    return ({k: sum(v) / len(v) * scale for k, v in tot.items()},
+            (sum(dur) / len(dur) * scale if dur else 0.0), n)
 
 
 shutil.copy(RAW / "bench_stats" / "bench_kernel_stats.csv", OUT / f"{ROUND}_bench_kernel_stats.csv")
@@ -38,7 +44,7 @@ c1, ms1, n1 = pmc("pmc1")
 c2, ms2, n2 = pmc("pmc2")
 cf, msf, nf = pmc("pmc_fetch")
 cw, msw, nw = pmc("pmc_write")
-checks = 134217728.0   # one launch of the 16,384-primer probe: 8,184 rows x 16,384 columns (approximately 2^27)
+checks = kLaunchChecks
 waves = checks / 64.0
 clock_ghz = c2["GRBM_GUI_ACTIVE"] / 8.0 / (ms2 * 1e-3) / 1e9
 simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
@@ -65,9 +71,10 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
-    "note": "each launch covers 2^27 ordered pairs; traffic = table loads of the 1,024 persistent blocks (148 KB each, mostly L2 hits), "
-            "the 64-byte atomics that set conflict bits (0.5 % of pairs) and the list of pairs handed to the later stages (about 5 %, 8 B each); "
-            "algorithmic bytes per launch are about 10 MB"}, indent=1))
+    "note": "scaled to one full launch of 2^27 ordered pairs; traffic = write-back of the spilled registers of the "
+            "three-wave kernel shape (scratch), the 64-byte atomics that set conflict bits (0.5 % of pairs), the list of "
+            "pairs handed to the later stages (about 7 %, 8 B each) and the table loads of the persistent blocks; "
+            "algorithmic bytes per launch are about 21 MB"}, indent=1))
 (OUT / "pmc_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "source": f"profiles/{ROUND}_pmc_{KERNEL}.txt",
     "valu_instructions_per_check": c1["SQ_INSTS_VALU"] / waves,
