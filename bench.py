@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 import msspe_amd
-from msspe_amd.distributed import gather_pool, reduce_counts, screen_row_block, shard_bounds
+from msspe_amd.distributed import all_reduce, gather_pool, reduce_counts, screen_row_block, shard_bounds
 
 K = 13
 THRESHOLD = -9000.0            # od-msspe/src/constants.rs:21
@@ -96,9 +96,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSSPE_BENCH_BACKEND=gloo + MSSPE_BENCH_DEVICE=0 rehearses the N > 1 path with several ranks
+    # on ONE card (tests only; RCCL refuses two ranks per device): never a reported number
+    backend = os.environ.get("MSSPE_BENCH_BACKEND", "nccl")
+    if backend != "nccl" and "MSSPE_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["MSSPE_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = max(args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -147,14 +155,16 @@ def main():
     stage = eng.pair_stage_stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t.item())
     checks_per_step = float(n) * float(n)
     value = checks_per_step * args.steps / elapsed
 
     if rank == 0:
         conflicts = int(d_conf.sum().item())
+        # position-weighted sum of the merged per-primer counts: equal for every sharding of the same pool
+        weights = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
+        conflict_checksum = int((d_conf.to(torch.int64) * weights).sum().item())
         # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^27 checks of this rank's block
         checks_rank = float(shard) * float(n) * args.steps
         per_launch_checks = checks_rank / max(launches, 1)
@@ -196,7 +206,8 @@ def main():
             "avg_launch_ms": per_launch_s * 1e3,
             "checks_per_launch": per_launch_checks,
             "executed": executed,
-            "retried_in_list_mode": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
+            "retried_in_list_mode": overflow / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
+            "flagged_ties": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
             "needed_f64_kernels": stage["needed_f64"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
             "hbm": {"achieved": bytes_per_launch / max(per_launch_s, 1e-12) / 1e9, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s",
@@ -217,8 +228,10 @@ def main():
                                    f"({checks_per_step:.3g} checks/step), thal ANY at od-msspe defaults "
                                    f"(mv 50, dv 3, dNTP 0, 250 nM, 25 C), threshold -9000 cal/mol",
                        "pool": n, "kmer_size": K, "checks_per_step": checks_per_step,
-                       "parallelism": f"row blocks x{world}" + (", all-gather pool + all-reduce counts (RCCL)" if world > 1 else ""),
-                       "conflicts": conflicts, "overflow_pairs_per_step": overflow / max(args.steps + args.warmup, 1)},
+                       "parallelism": f"row blocks x{world}" + (", all-gather pool + all-reduce counts "
+                                                                 f"({'RCCL' if backend == 'nccl' else backend + ' REHEARSAL'})" if world > 1 else ""),
+                       "conflicts": conflicts, "conflict_checksum": conflict_checksum,
+                       "overflow_pairs_per_step": overflow / max(args.steps + args.warmup, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

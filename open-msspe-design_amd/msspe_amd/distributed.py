@@ -7,7 +7,8 @@ screening round, both a few MB even at 1M candidates:
     all_gather_into_tensor   packed pool shards  -> full packed pool on every rank
     all_reduce(sum)          per-primer conflict counts (each rank contributes its rows)
 The conflict bitmap stays sharded by rows.  Works with backend "nccl" (= RCCL over xGMI) on GPUs
-and with "gloo" on CPU tensors (used by the tests to check the tiling logic itself).
+and with "gloo" (used by the tests to check the tiling logic itself: CPU tensors directly, device
+tensors staged through the host, which lets two ranks rehearse the path on one GPU).
 """
 from __future__ import annotations
 
@@ -22,6 +23,24 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """gloo has no device collectives here: stage device tensors through the host."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce(t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    """In-place all-reduce that also works for device tensors under gloo."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def gather_pool(local_shard: torch.Tensor, n: int) -> torch.Tensor:
     """All-gather the packed (int64) candidate shards into the full pool of n primers.
     Shards may differ in length by one: they are padded to the longest for the collective."""
@@ -31,8 +50,13 @@ def gather_pool(local_shard: torch.Tensor, n: int) -> torch.Tensor:
     longest = -(-n // world)
     padded = torch.zeros(longest, dtype=local_shard.dtype, device=local_shard.device)
     padded[: local_shard.numel()] = local_shard
-    out = torch.empty(longest * world, dtype=local_shard.dtype, device=local_shard.device)
-    dist.all_gather_into_tensor(out, padded)
+    if _staged(padded):
+        host = torch.empty(longest * world, dtype=local_shard.dtype)
+        dist.all_gather_into_tensor(host, padded.cpu())
+        out = host.to(local_shard.device)
+    else:
+        out = torch.empty(longest * world, dtype=local_shard.dtype, device=local_shard.device)
+        dist.all_gather_into_tensor(out, padded)
     parts = []
     for r in range(world):
         a, b = shard_bounds(n, world, r)
@@ -42,9 +66,7 @@ def gather_pool(local_shard: torch.Tensor, n: int) -> torch.Tensor:
 
 def reduce_counts(local_counts: torch.Tensor) -> torch.Tensor:
     """Sum the per-primer conflict counts of all ranks in place (each rank filled its rows)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(local_counts, op=dist.ReduceOp.SUM)
-    return local_counts
+    return all_reduce(local_counts, dist.ReduceOp.SUM)
 
 
 def screen_row_block(engine, d_pool: torch.Tensor, k: int, chem, threshold: float,
