@@ -245,3 +245,79 @@ def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypat
             assert np.isinf(a["dg"][r, c])
         else:
             assert a["dg"][r, c] == res.dG and a["tm"][r, c] == res.t
+
+
+def _read_bundle(path):
+    """{section: [lines]} of a parameter bundle ('@ name count' headers)."""
+    sections, name = {}, None
+    for line in path.read_text().splitlines():
+        if line.startswith("#") or not line.strip():
+            continue
+        if line.startswith("@"):
+            name = line.split()[1]
+            sections[name] = []
+        else:
+            sections[name].append(line)
+    return sections
+
+
+def _perturbed(sections, step_s, step_h):
+    """Shift every available entry of the stack / mismatch / terminal-stack / dangle entropies by
+    a multiple of step_s and the stack enthalpies by a multiple of step_h (tables stay plausible:
+    the point is that the engine computes with whatever the files hold)."""
+    out = {}
+    for name, lines in sections.items():
+        step = {"stack.ds": step_s, "stackmm.ds": step_s, "tstack2.ds": step_s, "tstack_tm_inf.ds": step_s,
+                "dangle.ds": step_s, "stack.dh": step_h}.get(name)
+        if step is None:
+            out[name] = list(lines)
+            continue
+        q, new = 0, []
+        for line in lines:
+            toks = []
+            for t in line.split():
+                if t != "inf":
+                    q += 1
+                    t = repr(round(float(t) + step * (q % 3 - 1), 6))
+                toks.append(t)
+            new.append(" ".join(toks))
+        out[name] = new
+    return out
+
+
+@pytest.mark.parametrize("mode", ["directory", "grid", "offgrid"])
+def test_parameter_files_from_a_path(m, oracle, tmp_path, mode):
+    """ntthal is run with `-path <primer3_config>/` (od-msspe/src/delta_g.rs:93-110): tables come from
+    files.  directory = the stock tables split into Primer3's 16 files; grid = shifted values that
+    still sit on the 0.01 cal/K grid (integer first stage, other numbers); offgrid = values off that
+    grid, for which the integer stage must stand down and the f64 kernels answer alone."""
+    sections = _read_bundle(oracle.default_bundle())
+    if mode == "grid":
+        sections = _perturbed(sections, 0.1, 100.0)
+    elif mode == "offgrid":
+        sections = _perturbed(sections, 0.003, 0.0)
+    if mode == "directory":
+        path = tmp_path / "primer3_config"
+        path.mkdir()
+        for name, lines in sections.items():
+            (path / name).write_text("\n".join(lines) + "\n")
+    else:
+        path = tmp_path / "custom.bundle"
+        path.write_text("# test bundle\n" + "".join(
+            f"@ {name} {sum(len(l.split()) for l in lines)}\n" + "\n".join(lines) + "\n"
+            for name, lines in sections.items()))
+    tables = oracle.Tables(path)
+    e = m.Engine(0, params_path=str(path))
+    try:
+        pool = m.synth.pool_strings(m.synth.random_pool(200, 13, seed=77))
+        out, _ = check_pool(e, m, oracle, tables, pool)
+        stats = e.pair_stage_stats()
+        if mode == "offgrid":
+            assert stats["deferred"] == 0 and stats["pick_tie"] == 0      # integer stage not used
+        else:
+            assert stats["pick_tie"] > 0                                  # integer stage ran
+        if mode != "directory":     # the perturbed tables really give other numbers
+            ref = oracle.pool_pairs(oracle.Tables(), pool)[1]
+            assert (out["dg"] != ref).mean() > 0.5
+    finally:
+        e.close()
