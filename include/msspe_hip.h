@@ -130,6 +130,10 @@ int msspe_pair_stage_samples(msspe_ctx *ctx, uint64_t *out, int capacity, int *n
 int msspe_host_pair_tables(const char *params_path, const msspe_chem *chem, float dg_threshold,
                            double *fast_S, int32_t *fast_H, int32_t *int_g, int32_t *int_T,
                            double consts[8]);
+/* The same for the long-oligo kernel (csrc/split_tables.hpp): S / H / g hold info[2] entries, L 1024,
+ * X info[3]; info = usable, longest oligo covered, entry count, X count. */
+int msspe_host_split_tables(const char *params_path, const msspe_chem *chem, double *S, int32_t *H,
+                            int32_t *g, int32_t *L, int32_t *X, int32_t info[4]);
 
 /* Full thal record for explicit pairs (a_i, b_i), i < n -- what `ntthal` prints per input line
  * (od-msspe/src/delta_g.rs:206-230): dS (salt-corrected), dH, dG, t and the base pairs of the

@@ -37,6 +37,8 @@ struct ChemEntry {
     bool fast_ok = false;
     IntTables *d_it = nullptr;    // integer image for the exact-integer kernel
     bool int_ok = false;
+    SplitTables *d_st = nullptr;  // long oligos (thal_pairs_split.hip)
+    int split_max_k = 0;          // 0: not usable
 };
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
@@ -141,6 +143,10 @@ int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntr
         e.int_ok = e.fast_ok && build_int_tables(*ft, pairs_fast_max_k(), *it);
         HIP_TRY(ctx, hipMalloc((void **)&e.d_it, sizeof(IntTables)));
         HIP_TRY(ctx, hipMemcpy(e.d_it, it.get(), sizeof(IntTables), hipMemcpyHostToDevice));
+        auto st = std::make_unique<SplitTables>();
+        e.split_max_k = build_split_tables(host_pt[0], chem.max_loop, *st) ? st->max_k : 0;
+        HIP_TRY(ctx, hipMalloc((void **)&e.d_st, sizeof(SplitTables)));
+        HIP_TRY(ctx, hipMemcpy(e.d_st, st.get(), sizeof(SplitTables), hipMemcpyHostToDevice));
     }
     ctx->chem_cache.push_back(e);
     *out = &ctx->chem_cache.back();
@@ -301,6 +307,7 @@ void msspe_destroy(msspe_ctx *ctx)
             if (e.d_pt) (void)hipFree(e.d_pt);
             if (e.d_ft) (void)hipFree(e.d_ft);
             if (e.d_it) (void)hipFree(e.d_it);
+            if (e.d_st) (void)hipFree(e.d_st);
         }
         if (ctx->wsS) (void)hipFree(ctx->wsS);
         if (ctx->wsH) (void)hipFree(ctx->wsH);
@@ -395,8 +402,10 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
 
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
-    const bool fast = !use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
-                      chem->max_loop >= 2 * k - 4;   // the tuned kernel has no loop-size cut-off
+    // long oligos: exact-integer kernel with a pair's table split over lanes (honours max_loop)
+    const bool split = !use_generic_only() && !use_f64_pairs() && k > pairs_fast_max_k() && k <= ce->split_max_k;
+    const bool fast = split || (!use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
+                                chem->max_loop >= 2 * k - 4);   // the tuned kernel has no loop-size cut-off
     // the conflict bitmap is produced with atomic ORs: clear the caller's block first
     if (d_bitmap)
         HIP_TRY(ctx, hipMemsetAsync(d_bitmap, 0, sizeof(uint64_t) * (size_t)(row1 - row0) * (size_t)words,
@@ -443,7 +452,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         }
         return MSSPE_OK;
     }
-    const bool int_stage = ce->int_ok && !use_f64_pairs();
+    const bool int_stage = !split && ce->int_ok && !use_f64_pairs();
     if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
     HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
                                              ctx->d_perm, ctx->stream));
@@ -469,6 +478,16 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         const uint2 *in_list = ctx->ovf_list;
         uint2 *out_list = ctx->ovf_list2;
         int in_c = 0, out_c = 1;
+        if (split) {   // what the split kernel handed on goes straight to the generic kernel
+            g.list = in_list;
+            g.list_count = ctx->ovf_count;
+            g.n_work = kListCap;
+            HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+            hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
+                               ctx->d_ovf_total);
+            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
+            return MSSPE_OK;
+        }
         auto advance = [&]() {   // the two buffers ping-pong: a stage's input is consumed when it ends
             in_list = out_list;
             out_list = out_list == ctx->ovf_list2 ? ctx->ovf_list : ctx->ovf_list2;
@@ -541,7 +560,8 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
-            if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->stream));
+            if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->stream));
+            else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
             if (ctx->prof_on)
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
@@ -948,6 +968,33 @@ int msspe_host_pair_tables(const char *params_path, const msspe_chem *chem, floa
     consts[5] = fast_ok ? 1.0 : 0.0;
     consts[6] = int_ok ? 1.0 : 0.0;
     consts[7] = (double)FastTables::kCount;
+    return MSSPE_OK;
+}
+
+int msspe_host_split_tables(const char *params_path, const msspe_chem *chem, double *S, int32_t *H,
+                            int32_t *g, int32_t *L, int32_t *X, int32_t info[4])
+{
+    // host only: what the long-oligo kernel keeps in LDS (csrc/split_tables.hpp)
+    if (!chem || !S || !H || !g || !L || !X || !info) return MSSPE_ERR_ARG;
+    auto tb = std::make_unique<NNTables>();
+    std::string err;
+    const std::string path = params_path && *params_path ? params_path : default_bundle_path();
+    if (!load_nn_tables(path, *tb, err)) return MSSPE_ERR_TABLES;
+    const ThalConsts c = make_dimer_consts(chem->mv, chem->dv, chem->dntp, chem->dna_conc, chem->temp_c,
+                                           chem->max_loop, false, -9000.0f);
+    auto pt = std::make_unique<PairTables>();
+    if (!build_pair_tables(*tb, c, *pt, err)) return MSSPE_ERR_TABLES;
+    auto st = std::make_unique<SplitTables>();
+    build_split_tables(*pt, chem->max_loop, *st);
+    std::memcpy(S, st->S, sizeof st->S);
+    std::memcpy(H, st->H, sizeof st->H);
+    std::memcpy(g, st->g, sizeof st->g);
+    std::memcpy(L, st->L, sizeof st->L);
+    std::memcpy(X, st->X, sizeof st->X);
+    info[0] = st->usable;
+    info[1] = st->max_k;
+    info[2] = SplitTables::kCount;
+    info[3] = SplitTables::kXCount;
     return MSSPE_OK;
 }
 

@@ -7,6 +7,7 @@
 
 #include "fast_tables.hpp"
 #include "nn_params.hpp"
+#include "split_tables.hpp"
 
 namespace msspe {
 
@@ -94,6 +95,11 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
 // 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
                                  const uint32_t *in_count, unsigned long long *reasons, hipStream_t stream);
+// Long oligos (17 .. SplitTables::max_k bases, thal_pairs_split.hip): exact-integer first stage with
+// a pair's table split over 2 or 4 lanes; same contract as launch_pairs_int (a.ft is not used).
+hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
+                              hipStream_t stream);
+int pairs_split_lanes(int k);
 int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();

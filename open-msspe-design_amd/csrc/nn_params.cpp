@@ -7,6 +7,7 @@
 // getTetraloop readers, restated from SURVEY.md Appendix C.1.
 #include "nn_params.hpp"
 #include "fast_tables.hpp"
+#include "split_tables.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -443,12 +444,11 @@ double g_cut(float threshold)
     return from_key(lo);
 }
 
-bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastTables &out)
+// The compact S / H planes shared by FastTables and SplitTables (same layout, other loop-size
+// range): T provides the k* offsets, kMaxSz, S[] and H[].
+template <class T>
+static void fill_compact_planes(const PairTables &pt, T &out, bool &ok, double &min_S)
 {
-    (void)t;
-    std::memset(&out, 0, sizeof out);
-    bool ok = pt.h_is_integral != 0;
-    double min_S = 0.0;     // most negative entropy any single table term can add
     auto put = [&](int idx, double S, int32_t H) {
         // an unavailable entry carries a huge positive entropy next to its huge enthalpy, so that
         // the kernel's single rejection test "H > 0 and S > 0" (thal.c's both-positive rule)
@@ -465,16 +465,16 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
     const int32_t atH[4] = {2200, 0, 0, 2200};
     // po = a | oa << 2 | ob << 4  ->  PairTables index (a*4 + oa)*4 + ob
     auto src_of = [](int po) { return ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4); };
-    for (int sz = 2; sz <= FastTables::kMaxSz; ++sz)
+    for (int sz = 2; sz <= T::kMaxSz; ++sz)
         for (int po = 0; po < 64; ++po) {
-            const int idx = FastTables::kNB + (sz - 2) * 64 + po;
+            const int idx = T::kNB + (sz - 2) * 64 + po;
             if (sz == 2) put(idx, pt.mm_S[src_of(po)], pt.mm_H[src_of(po)]);
             else put(idx, pt.loopS[0][sz - 1] + pt.ts_S[src_of(po)], addH(pt.loopH[0][sz - 1], pt.ts_H[src_of(po)]));
         }
     for (int ac = 0; ac < 4; ++ac)
-        for (int sz = 0; sz <= FastTables::kMaxSz; ++sz)
+        for (int sz = 0; sz <= T::kMaxSz; ++sz)
             for (int ap = 0; ap < 4; ++ap) {
-                const int idx = FastTables::kBU + ac * FastTables::kBUStride + sz * 4 + ap;
+                const int idx = T::kBU + ac * T::kBUStride + sz * 4 + ap;
                 double S = -1.0;
                 int32_t H = kHInf;
                 if (sz == 1) {
@@ -491,17 +491,26 @@ bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastT
                 put(idx, S, H);
             }
     for (int ci = 0; ci < 64; ++ci) {
-        put(FastTables::kTSc + ci, pt.ts_S[ci], pt.ts_H[ci]);   // cell side: (x*4+y)*4+z already
-        put(FastTables::kMMc + ci, pt.mm_S[ci], pt.mm_H[ci]);
+        put(T::kTSc + ci, pt.ts_S[ci], pt.ts_H[ci]);   // cell side: (x*4+y)*4+z already
+        put(T::kMMc + ci, pt.mm_S[ci], pt.mm_H[ci]);
     }
-    for (int q = 0; q < 4; ++q) put(FastTables::kZero + q, 0.0, 0);
+    for (int q = 0; q < 4; ++q) put(T::kZero + q, 0.0, 0);
     const double ilas = (-300 / 310.15);
-    for (int d = -32; d < 32; ++d) put(FastTables::kZT + 32 + d, ilas * (d < 0 ? -d : d), 0);
+    for (int d = -32; d < 32; ++d) put(T::kZT + 32 + d, ilas * (d < 0 ? -d : d), 0);
     for (int q = 0; q < 100; ++q) {
-        put(FastTables::kEndL + q, pt.endL_S[q], pt.endL_H[q]);
-        put(FastTables::kEndR + q, pt.endR_S[q], pt.endR_H[q]);
+        put(T::kEndL + q, pt.endL_S[q], pt.endL_H[q]);
+        put(T::kEndR + q, pt.endR_S[q], pt.endR_H[q]);
     }
-    for (int q = 0; q < 16; ++q) put(FastTables::kWC + q, pt.wc_S[q], pt.wc_H[q]);
+    for (int q = 0; q < 16; ++q) put(T::kWC + q, pt.wc_S[q], pt.wc_H[q]);
+}
+
+bool build_fast_tables(const NNTables &t, const PairTables &pt, int max_k, FastTables &out)
+{
+    (void)t;
+    std::memset(&out, 0, sizeof out);
+    bool ok = pt.h_is_integral != 0;
+    double min_S = 0.0;     // most negative entropy any single table term can add
+    fill_compact_planes(pt, out, ok, min_S);
     // clamp reachability: a path has at most max_k pairs and every step adds at most three table
     // terms, each >= min_S; plus two end terms
     if (3.0 * min_S * (max_k + 2) < -2500.0) ok = false;
@@ -582,6 +591,135 @@ bool build_int_tables(const FastTables &ft, int max_k, IntTables &out)
     out.usable = ok ? 1 : 0;
     out.max_k = max_k;
     return ok;
+}
+
+bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
+{
+    typedef SplitTables W;
+    std::memset(&out, 0, sizeof out);
+    bool ok = pt.h_is_integral != 0;
+    double min_S = 0.0;
+    fill_compact_planes(pt, out, ok, min_S);
+    // integer image of one (S, H) term
+    auto gi = [&](double S, int32_t H) -> int32_t {
+        if (H >= kHInf) return W::kBig;
+        const double s100 = S * 100.0, r = std::nearbyint(s100);
+        if (std::fabs(s100 - r) > 1e-7 || std::fabs(r) > 1e5 || H % 10 != 0) {
+            ok = false;
+            return W::kBig;
+        }
+        return (int32_t)((long)W::kGh * (H / 10) - (long)W::kGs * (long)r);
+    };
+    for (int e = 0; e < W::kCount; ++e) {
+        if (e >= W::kZT && e < W::kZT + 64) {   // asymmetry: carried as n
+            const int d = e - (W::kZT + 32);
+            out.g[e] = W::kGn * (d < 0 ? -d : d);
+        } else {
+            out.g[e] = gi(out.S[e], out.H[e]);
+        }
+    }
+    auto src_of = [](int po) { return ((po & 3) * 4 + ((po >> 2) & 3)) * 4 + (po >> 4); };
+    const int lim = std::min(max_loop, W::kMaxSz);
+    for (int d = 0; d < 1024; ++d) {
+        const int l1 = d >> 5, l2 = d & 31, sz = l1 + l2;
+        int32_t v = W::kBig;
+        if (d != 0 && sz <= lim) {
+            if (l1 == 0 || l2 == 0 || d == 0x21) v = 0;
+            else {
+                v = gi(pt.loopS[0][sz - 1], pt.loopH[0][sz - 1]);
+                if (v != W::kBig) v += W::kGn * (l1 > l2 ? l1 - l2 : l2 - l1);
+            }
+        }
+        out.L[d] = v;
+    }
+    for (int po = 0; po < 64; ++po) {
+        out.X[W::kXP + po] = gi(pt.ts_S[src_of(po)], pt.ts_H[src_of(po)]);
+        out.X[W::kXMM + po] = gi(pt.mm_S[src_of(po)], pt.mm_H[src_of(po)]);
+    }
+    for (int sz = 0; sz < 32; ++sz)
+        for (int pe = 0; pe < 16; ++pe) {
+            const int32_t v = (sz >= 1 && sz <= W::kMaxSz)
+                                  ? out.g[W::kBU + (pe >> 2) * W::kBUStride + sz * 4 + (pe & 3)] : W::kBig;
+            out.X[W::kXB1 + sz * 16 + pe] = v;
+            out.X[W::kXB2 + sz * 16 + pe] = v;
+        }
+    // the two-part loop term must reproduce the folded entry (it does when both parts sit on the grid)
+    for (int sz = 3; sz <= W::kMaxSz && ok; ++sz)
+        for (int po = 0; po < 64; ++po) {
+            const int32_t whole = out.g[W::kNB + (sz - 2) * 64 + po];
+            const int32_t a = gi(pt.loopS[0][sz - 1], pt.loopH[0][sz - 1]), b = out.X[W::kXP + po];
+            if (whole == W::kBig || a == W::kBig || b == W::kBig) {
+                if (!(whole == W::kBig && (a == W::kBig || b == W::kBig))) ok = false;
+            } else if (whole != a + b) ok = false;
+        }
+    // Ranges.  A stored cell value is the left end term plus stacked pairs plus accepted loops.  A
+    // loop is only accepted when it LOWERS the value, a stacked pair adds g(wc): so the value never
+    // exceeds (largest end term) + (stacks) * max(0, g(wc)); from below it is bounded per base
+    // spent (a path uses the 2 k bases of the two oligos, a stacked pair costs 2, a loop of size sz
+    // costs sz + 2) by the most negative term sums.  Enthalpy and entropy: magnitudes per base.
+    auto gv = [&](int e) -> double { return out.g[e] == W::kBig ? 0.0 : (double)out.g[e]; };
+    auto hmag = [&](int e) -> double { return out.H[e] >= kHInf ? 0.0 : std::fabs((double)out.H[e]); };
+    auto sneg = [&](int e) -> double { return (out.H[e] >= kHInf || out.S[e] > 0) ? 0.0 : -out.S[e]; };
+    double gneg = 0, gpos_wc = 0, hb = 0, sb = 0, gmm_lo = 0, hmm = 0, smm = 0, gen = 0, hen = 0, sen = 0;
+    for (int e = W::kWC; e < W::kWC + 16; ++e) {
+        gneg = std::max(gneg, -gv(e) / 2.0);
+        gpos_wc = std::max(gpos_wc, gv(e));
+        hb = std::max(hb, hmag(e) / 2.0);
+        sb = std::max(sb, sneg(e) / 2.0);
+    }
+    for (int e = W::kTSc; e < W::kZero; ++e) {
+        gmm_lo = std::max(gmm_lo, -gv(e));
+        hmm = std::max(hmm, hmag(e));
+        smm = std::max(smm, sneg(e));
+    }
+    for (int sz = 2; sz <= W::kMaxSz; ++sz)
+        for (int po = 0; po < 64; ++po) {
+            const int e = W::kNB + (sz - 2) * 64 + po;
+            gneg = std::max(gneg, (-gv(e) + gmm_lo) / (sz + 2));   // the asymmetry term is >= 0
+            hb = std::max(hb, (hmag(e) + hmm) / (sz + 2));
+            sb = std::max(sb, (sneg(e) + smm + 0.97 * sz) / (sz + 2));
+        }
+    for (int ac = 0; ac < 4; ++ac)
+        for (int sz = 1; sz <= W::kMaxSz; ++sz)
+            for (int ap = 0; ap < 4; ++ap) {
+                const int e = W::kBU + ac * W::kBUStride + sz * 4 + ap;
+                gneg = std::max(gneg, -gv(e) / (sz + 2));
+                hb = std::max(hb, hmag(e) / (sz + 2));
+                sb = std::max(sb, sneg(e) / (sz + 2));
+            }
+    for (int e = W::kEndL; e < W::kWC; ++e) {
+        gen = std::max(gen, std::fabs(gv(e)));
+        hen = std::max(hen, hmag(e));
+        sen = std::max(sen, sneg(e));
+    }
+    // a candidate in flight adds one loop term, one predecessor-side and one cell-side term
+    double cand_hi = 0;
+    for (int d = 1; d < 1024; ++d)
+        if (out.L[d] != W::kBig) cand_hi = std::max(cand_hi, (double)out.L[d]);
+    {
+        double x_hi = 0, y_hi = 0;
+        for (int e = 0; e < W::kXCount; ++e)
+            if (out.X[e] != W::kBig) x_hi = std::max(x_hi, (double)out.X[e]);
+        for (int e = W::kTSc; e < W::kZero; ++e) y_hi = std::max(y_hi, gv(e));
+        cand_hi += x_hi + y_hi;
+    }
+    if (std::getenv("MSSPE_DEBUG_BOUNDS"))
+        std::fprintf(stderr, "split bounds: ok %d gneg %g gpos_wc %g hb %g sb %g gmm_lo %g gen %g hen %g cand_hi %g\n",
+                     (int)ok, gneg, gpos_wc, hb, sb, gmm_lo, gen, hen, cand_hi);
+    int max_k = 0;
+    for (int k = 32; k >= 2 && ok; --k) {
+        const bool fits = 2.0 * k * gneg + 2.0 * gen + gmm_lo < (double)W::kReach &&     // int32 sums, low side
+                          2.0 * gen + k * gpos_wc + cand_hi < (double)W::kReach &&         // ... high side
+                          2.0 * k * hb + 2.0 * hen + hmm + 200.0 < 327000.0 &&      // H / 10 in 16 bits
+                          2.0 * k * sb + 2.0 * sen + smm + 6.0 < 2400.0;            // MinEntropyCutoff (-2500) out of reach
+        if (fits) {
+            max_k = k;
+            break;
+        }
+    }
+    out.usable = (ok && max_k >= 2) ? 1 : 0;
+    out.max_k = out.usable ? max_k : 0;
+    return out.usable != 0;
 }
 
 }  // namespace msspe

@@ -14,14 +14,14 @@ namespace msspe {
 
 namespace {
 
-constexpr int kBins = 17 * 17 * 17;   // (count_A, count_C, count_G) for oligos up to 16 bases
+constexpr int kBins = 33 * 33 * 33;   // (count_A, count_C, count_G) for oligos up to 32 bases
 
 __device__ __forceinline__ int composition_bin(uint64_t w, int k)
 {
     int cnt[4] = {0, 0, 0, 0};
     for (int p = 0; p < k; ++p) cnt[(w >> (2 * p)) & 3]++;
     // order bins so that neighbours differ little: T-rich ... A-rich along the major axis
-    return (cnt[0] * 17 + cnt[1]) * 17 + cnt[2];
+    return (cnt[0] * 33 + cnt[1]) * 33 + cnt[2];
 }
 
 __global__ void k_hist(const uint64_t *pool, int col0, int ncols, int k, uint32_t *bins)

@@ -77,9 +77,11 @@ def test_edge_pools(eng, m, oracle, oracle_tables):
     assert np.isfinite(out["dg"][0, 1])
 
 
-@pytest.mark.parametrize("k", [6, 8, 12, 16, 20, 27])
+@pytest.mark.parametrize("k", [6, 8, 12, 16, 17, 20, 21, 24, 27, 28, 29, 32])
 def test_other_oligo_lengths(eng, m, oracle, oracle_tables, k):
-    pool = m.synth.pool_strings(m.synth.random_pool(24 if k <= 16 else 10, k, seed=100 + k))
+    """k <= 16: register-table kernels; 17 .. 28: the table split over 2 or 4 lanes
+    (thal_pairs_split.hip); longer: the generic kernel."""
+    pool = m.synth.pool_strings(m.synth.random_pool(24 if k <= 16 else (40 if k <= 28 else 10), k, seed=100 + k))
     if k % 2 == 0:   # both-self-complementary pairs use the symmetric concentration term
         half = pool[0][:k // 2]
         pal = half + oracle.reverse_complement(half)
@@ -319,5 +321,44 @@ def test_parameter_files_from_a_path(m, oracle, tmp_path, mode):
         if mode != "directory":     # the perturbed tables really give other numbers
             ref = oracle.pool_pairs(oracle.Tables(), pool)[1]
             assert (out["dg"] != ref).mean() > 0.5
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("k,max_loop", [(18, 30), (20, 30), (22, 6), (26, 30)])
+def test_long_oligo_stage_equals_generic_kernel(m, oracle, oracle_tables, monkeypatch, k, max_loop):
+    """The split-table integer stage (17 .. 28 bases) against the dense f64 kernel on a pool the
+    oracle would need minutes for: same decisions, same counts; a sample of rows bit-exact against
+    the oracle; a loop-size limit below 30 is honoured (thal.c maxLoop)."""
+    n = 768
+    pool = m.synth.pool_strings(m.synth.random_pool(n, k, seed=4000 + k))
+    # a few designed cases: perfect duplexes, a self-complementary pair, homopolymers
+    pool[1] = oracle.reverse_complement(pool[0])
+    half = pool[2][:k // 2]
+    pool[3] = half + oracle.reverse_complement(half)
+    pool[4], pool[5] = "A" * k, "T" * k
+    chem = m.Chem.ntthal()
+    chem.max_loop = max_loop
+    e = m.Engine(0)
+    try:
+        fast = e.cross_dimer(pool, chem, -9000.0)
+        stats = e.pair_stage_stats()
+        handed_on = e.last_overflow_pairs()
+        monkeypatch.setenv("MSSPE_FORCE_GENERIC", "1")
+        slow = e.cross_dimer(pool, chem, -9000.0)
+        monkeypatch.delenv("MSSPE_FORCE_GENERIC")
+        np.testing.assert_array_equal(fast["bitmap"], slow["bitmap"])
+        np.testing.assert_array_equal(fast["row_conflicts"], slow["row_conflicts"])
+        assert fast["row_conflicts"].sum() > 0
+        assert 0 < handed_on < 0.05 * n * n          # the integer stage answered nearly everything
+        assert stats["replay_mismatch"] == 0 and stats["tm_near_tie"] == 0
+        rows = (0, 2, 4, 5, 300, n - 1)
+        sub = e.cross_dimer([pool[r] for r in rows] + pool, chem, -9000.0, want_dg=True, want_tm=True)
+        oargs = oracle.ntthal_args(max_loop=max_loop)
+        for q, r in enumerate(rows):
+            _, dg, cf, tt = oracle.pool_pairs(oracle_tables, [pool[r]] + pool, oargs, -9000.0, want_t=True,
+                                             rows=(0, 1))
+            np.testing.assert_array_equal(sub["dg"][q, len(rows):], dg[0, 1:])
+            np.testing.assert_array_equal(sub["tm"][q, len(rows):], tt[0, 1:])
     finally:
         e.close()

@@ -12,19 +12,21 @@ import msspe_amd as m
 
 
 def main():
+    import os
     sizes = [int(x) for x in sys.argv[1:]] or [2048, 8192]
+    K = int(os.environ.get("MSSPE_PROBE_K", "13"))
     eng = m.Engine(0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     chem = m.Chem.ntthal()
     for n in sizes:
-        pool = m.pack_oligos(m.synth.random_pool(n, 13))
+        pool = m.pack_oligos(m.synth.random_pool(n, K))
         d_pool = torch.from_numpy(pool.view(np.int64)).cuda()
         words = (n + 63) // 64
         d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
         d_bm = torch.zeros((n, words), dtype=torch.int64, device="cuda")
         def run():
             d_rc.zero_()
-            eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, chem, -9000.0, (0, n), (0, n),
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, K, chem, -9000.0, (0, n), (0, n),
                                 d_rc.data_ptr(), d_bm.data_ptr())
         run()
         torch.cuda.synchronize()
@@ -43,7 +45,7 @@ def main():
             nl, ms = eng.profile_read()
             print(f'   first-stage launches {nl}, avg {ms/max(nl,1):.3f} ms per launch', flush=True)
             eng.profile_enable(False)
-        print(f"n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
+        print(f"k={K} n={n}: {dt*1e3:.1f} ms/pass, {n*n/dt/1e6:.1f} M checks/s, conflicts={int(d_rc.sum())}, "
               f"overflow pairs={ovf} ({100.0*ovf/(n*n):.2f} %)", flush=True)
         print("   integer stage:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats.items() if not isinstance(v, dict)},
               "| list mode:", {k: f"{100.0*v/(n*n):.3f} %" for k, v in stats["list"].items() if v}, flush=True)
