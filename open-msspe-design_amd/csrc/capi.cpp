@@ -39,6 +39,7 @@ struct ChemEntry {
     bool int_ok = false;
     SplitTables *d_st = nullptr;  // long oligos (thal_pairs_split.hip)
     int split_max_k = 0;          // 0: not usable
+    int wave_max_k = 0;           // f64 one-wave-per-pair kernel (thal_pairs_wave.hip)
 };
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
@@ -145,6 +146,7 @@ int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntr
         HIP_TRY(ctx, hipMemcpy(e.d_it, it.get(), sizeof(IntTables), hipMemcpyHostToDevice));
         auto st = std::make_unique<SplitTables>();
         e.split_max_k = build_split_tables(host_pt[0], chem.max_loop, *st) ? st->max_k : 0;
+        e.wave_max_k = st->f64_max_k;
         HIP_TRY(ctx, hipMalloc((void **)&e.d_st, sizeof(SplitTables)));
         HIP_TRY(ctx, hipMemcpy(e.d_st, st.get(), sizeof(SplitTables), hipMemcpyHostToDevice));
     }
@@ -227,6 +229,14 @@ bool use_generic_only()
 {
     const char *e = std::getenv("MSSPE_FORCE_GENERIC");
     return e && *e && *e != '0';
+}
+
+// Shortest oligo that goes to the split-table kernel (thal_pairs_split.hip) instead of the
+// register-table chain; MSSPE_SPLIT_MIN_K overrides it (experiments).
+int split_min_k()
+{
+    if (const char *e = std::getenv("MSSPE_SPLIT_MIN_K")) return std::atoi(e);
+    return 15;   // measured on 8,192 primers: k = 14 register tables 516 vs 250 M checks/s, k = 15 198 vs 202, k = 16 41 vs 165
 }
 
 // MSSPE_PAIR_KERNEL=f64 keeps the f64 register-table kernel as the first stage (testing aid);
@@ -403,9 +413,14 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
     // long oligos: exact-integer kernel with a pair's table split over lanes (honours max_loop)
-    const bool split = !use_generic_only() && !use_f64_pairs() && k > pairs_fast_max_k() && k <= ce->split_max_k;
-    const bool fast = split || (!use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
-                                chem->max_loop >= 2 * k - 4);   // the tuned kernel has no loop-size cut-off
+    const bool split = !use_generic_only() && !use_f64_pairs() && k >= split_min_k() && k <= ce->split_max_k;
+    // f64, one wave per pair: behind the split kernel, and as the first stage where neither the split
+    // kernel nor the register-table chain applies (29 .. 32 bases, parameter files off the grid)
+    const bool wave_ok = !use_generic_only() && k <= ce->wave_max_k && std::getenv("MSSPE_NO_WAVE_KERNEL") == nullptr;
+    const bool wave_matrix = wave_ok && !split && k > pairs_fast_max_k();
+    const bool fast = split || wave_matrix ||
+                      (!use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
+                       chem->max_loop >= 2 * k - 4);   // the tuned kernel has no loop-size cut-off
     // the conflict bitmap is produced with atomic ORs: clear the caller's block first
     if (d_bitmap)
         HIP_TRY(ctx, hipMemsetAsync(d_bitmap, 0, sizeof(uint64_t) * (size_t)(row1 - row0) * (size_t)words,
@@ -453,9 +468,11 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         return MSSPE_OK;
     }
     const bool int_stage = !split && ce->int_ok && !use_f64_pairs();
-    if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
-    HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
-                                             ctx->d_perm, ctx->stream));
+    if (!wave_matrix) {
+        if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
+        HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
+                                                 ctx->d_perm, ctx->stream));
+    }
     // Overflow pairs are collected over several launches and finished together: the list kernels
     // have a fixed latency floor, and list_cap entries cannot be overrun by list_cap / kChunkPairs
     // launches even if every pair overflowed.
@@ -478,9 +495,19 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         const uint2 *in_list = ctx->ovf_list;
         uint2 *out_list = ctx->ovf_list2;
         int in_c = 0, out_c = 1;
-        if (split) {   // what the split kernel handed on goes straight to the generic kernel
+        if (split || wave_matrix) {
+            // long oligos: what the split kernel handed on is answered in f64 by one wave per pair;
+            // the dense kernel takes what is left (two self-complementary oligos, huge tables)
+            if (split && wave_ok) {
+                a.overflow_list = out_list;
+                a.overflow_count = ctx->ovf_count + out_c;
+                a.overflow_cap = (uint32_t)kListCap;
+                HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, in_list, ctx->ovf_count + in_c, ctx->stream));
+                in_list = out_list;
+                in_c = out_c;
+            }
             g.list = in_list;
-            g.list_count = ctx->ovf_count;
+            g.list_count = ctx->ovf_count + in_c;
             g.n_work = kListCap;
             HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
             hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
@@ -560,7 +587,11 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used].first, ctx->stream));
             }
-            if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->stream));
+            if (wave_matrix) {
+                a.col0 = col0 + (int)q0;   // pool columns, no composition sort
+                a.col1 = col0 + (int)q_end;
+                HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
+            } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->stream));
             else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
             if (ctx->prof_on)

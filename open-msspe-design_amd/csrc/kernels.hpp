@@ -100,6 +100,12 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
                               hipStream_t stream);
 int pairs_split_lanes(int k);
+// f64 DP with one wave per pair (thal_pairs_wave.hip), oligos up to st->f64_max_k bases.  in_list:
+// explicit pairs (count *in_count, at most a.overflow_cap); nullptr: the block rows [a.row0, a.row1) x
+// pool columns [a.col0, a.col1).  Pairs it does not take (two self-complementary oligos, oversized
+// tables) are appended to a.overflow_list for launch_dimer_generic.
+hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, const uint2 *in_list,
+                             const uint32_t *in_count, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();

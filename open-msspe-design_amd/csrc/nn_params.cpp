@@ -600,6 +600,7 @@ bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
     bool ok = pt.h_is_integral != 0;
     double min_S = 0.0;
     fill_compact_planes(pt, out, ok, min_S);
+    const bool planes_ok = ok;
     // integer image of one (S, H) term
     auto gi = [&](double S, int32_t H) -> int32_t {
         if (H >= kHInf) return W::kBig;
@@ -719,6 +720,12 @@ bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
     }
     out.usable = (ok && max_k >= 2) ? 1 : 0;
     out.max_k = out.usable ? max_k : 0;
+    out.f64_max_k = 0;
+    for (int k = 32; k >= 2 && planes_ok; --k)
+        if (2.0 * k * sb + 2.0 * sen + smm + 6.0 < 2400.0) {
+            out.f64_max_k = k;
+            break;
+        }
     return out.usable != 0;
 }
 

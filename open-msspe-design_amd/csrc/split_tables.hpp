@@ -55,6 +55,8 @@ struct SplitTables {
     int32_t X[kXCount];
     int32_t usable;          // 0: the preconditions do not hold, use the generic kernel
     int32_t max_k;           // longest oligo the range checks cover (0 if unusable)
+    int32_t f64_max_k;       // longest oligo for which the S / H planes alone are exact for an f64 DP
+                             // (thal_pairs_wave.hip): integral enthalpies, MinEntropyCutoff out of reach
 };
 
 // max_loop: the chemistry's loop-size limit (thal.c maxLoop, <= 30).  Returns out.usable != 0.
