@@ -60,7 +60,7 @@ struct msspe_ctx {
     size_t ws_cells = 0;
     uint2 *ovf_list = nullptr;         // pairs the main kernel could not hold
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
-    uint32_t *ovf_count = nullptr;     // list counters of the stages: [0] first, [1] second, [2] third
+    uint32_t *ovf_count = nullptr;     // list counters of the stages (8): [0] first, [1] second, ...
     long list_cap = 0;                 // entries per hand-over list
     uint64_t *d_ovf_total = nullptr;
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
@@ -195,9 +195,9 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want));
     ctx->list_cap = want;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 4));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 8));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 4));
+    HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 8));
     HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024 + 8) * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (9 + 1024 + 8) * sizeof(unsigned long long)));
@@ -512,7 +512,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
             hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
                                ctx->d_ovf_total);
-            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
             return MSSPE_OK;
         }
         auto advance = [&]() {   // the two buffers ping-pong: a stage's input is consumed when it ends
@@ -540,17 +540,24 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         a.overflow_count = ctx->ovf_count + out_c;
         a.overflow_cap = (uint32_t)kListCap;
         HIP_TRY(ctx, launch_pairs_wide(a, in_list, ctx->ovf_count + in_c, ctx->stream));
-        // last stage: whatever is left (huge tables, both-self-complementary pairs)
+        if (wave_ok) {
+            // huge tables: one wave per pair, the table in LDS
+            advance();
+            a.overflow_list = out_list;
+            a.overflow_count = ctx->ovf_count + out_c;
+            HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, in_list, ctx->ovf_count + in_c, ctx->stream));
+        }
+        // last stage: whatever is left (both-self-complementary pairs)
         g.list = out_list;
         g.list_count = ctx->ovf_count + out_c;
         g.n_work = kListCap;
         HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
         hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
                            ctx->d_ovf_total);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
         return MSSPE_OK;
     };
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 4 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
     long pending = 0;   // worst-case entries the list may hold
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
         const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
