@@ -64,14 +64,21 @@ struct MasksS {
     unsigned long long tie, multi, stHave;   // multi: three or more candidates share the minimum
 };
 
-__device__ __forceinline__ void visit_s(const ICellS &c, const char *L, const char *X, int Gp, int Wp,
-                                        IBestS &best, IBestS &stk, MasksS &m)
+// One predecessor slot against the cell, in three phases so that a chunk issues all its LDS gathers
+// before any is consumed: geometry (integer VALU) -> two gathers -> finish.
+struct VisitS {
+    int li4, xi4;   // byte offsets into L and X
+    int y;          // cell-side term for this kind of loop
+    bool stack;     // the predecessor is the cell (i-1, j-1)
+};
+__device__ __forceinline__ VisitS visit_geo_s(const ICellS &c, int Wp)
 {
+    VisitS v;
     const int gp = Wp & 0x3ff;
     const int d = c.cgeo - gp;
     const int jj = Wp & 31;
     const bool geo = (jj <= c.jm1p) & (d >= 0);
-    const bool stack = gp == c.cstk;
+    v.stack = gp == c.cstk;
     const bool l1z = d < 32, l2z = jj == c.jm1p;
     const bool bulge = l1z | l2z;
     const int po4 = (Wp >> 8) & 0xfc;
@@ -80,10 +87,15 @@ __device__ __forceinline__ void visit_s(const ICellS &c, const char *L, const ch
     const bool m11 = d == 0x21;
     const int xi4 = bulge ? bx4 : (po4 + (m11 ? 4 * W_::kXMM : 0));
     // an impossible geometry reads L[0] = kBig (the stacked pair's row) and X[0]
-    const int lv = *(const int *)(L + (geo ? (d << 2) : 0));
-    const int xv = *(const int *)(X + (geo ? xi4 : 0));
-    const int y = m11 ? c.yMM : (bulge ? 0 : c.yTS);
-    const int cand = lv + xv + y + Gp;
+    v.li4 = geo ? (d << 2) : 0;
+    v.xi4 = geo ? xi4 : 0;
+    v.y = m11 ? c.yMM : (bulge ? 0 : c.yTS);
+    return v;
+}
+__device__ __forceinline__ void visit_fin_s(const VisitS &v, int lv, int xv, int Gp, int Wp, IBestS &best,
+                                            IBestS &stk, MasksS &m)
+{
+    const int cand = lv + xv + v.y + Gp;
     const bool better = cand < best.G;
     const bool eq = cand == best.G;
     const unsigned long long bm = __builtin_amdgcn_ballot_w64(better), em = __builtin_amdgcn_ballot_w64(eq);
@@ -92,9 +104,9 @@ __device__ __forceinline__ void visit_s(const ICellS &c, const char *L, const ch
     best.G = better ? cand : best.G;
     best.W = better ? Wp : best.W;
     best.W2 = eq ? Wp : best.W2;
-    stk.G = stack ? Gp : stk.G;
-    stk.W = stack ? Wp : stk.W;
-    m.stHave |= __builtin_amdgcn_ballot_w64(stack);
+    stk.G = v.stack ? Gp : stk.G;
+    stk.W = v.stack ? Wp : stk.W;
+    m.stHave |= __builtin_amdgcn_ballot_w64(v.stack);
 }
 
 __device__ __forceinline__ int slot_s(const v32i a, const v32i b, int x)
@@ -112,9 +124,18 @@ __device__ __forceinline__ void scan_s(const v32i Ga, const v32i Wa, const v32i 
     if constexpr (PC * kC < kLaneSlots) {
         if (PC * kC < upto) {   // wave-uniform
             asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
+            VisitS v[kC];
+            int lv[kC], xv[kC];
+#pragma unroll
+            for (int e = 0; e < kC; ++e) v[e] = visit_geo_s(c, slot_s(Wa, Wb, PC * kC + e));
+#pragma unroll
+            for (int e = 0; e < kC; ++e) {
+                lv[e] = *(const int *)(L + v[e].li4);
+                xv[e] = *(const int *)(X + v[e].xi4);
+            }
 #pragma unroll
             for (int e = 0; e < kC; ++e)
-                visit_s(c, L, X, slot_s(Ga, Gb, PC * kC + e), slot_s(Wa, Wb, PC * kC + e), best, stk, m);
+                visit_fin_s(v[e], lv[e], xv[e], slot_s(Ga, Gb, PC * kC + e), slot_s(Wa, Wb, PC * kC + e), best, stk, m);
             scan_s<PC + 1>(Ga, Wa, Gb, Wb, upto, L, X, c, best, stk, m);
         }
     }
