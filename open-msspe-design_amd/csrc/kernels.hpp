@@ -96,7 +96,7 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
                                  const uint32_t *in_count, unsigned long long *reasons, hipStream_t stream);
 // Long oligos (17 .. SplitTables::max_k bases, thal_pairs_split.hip): exact-integer first stage with
-// a pair's table split over 2 or 4 lanes; same contract as launch_pairs_int (a.ft is not used).
+// a pair's table split over 2, 4 or 8 lanes; same contract as launch_pairs_int (a.ft is not used).
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
                               hipStream_t stream);
 int pairs_split_lanes(int k);

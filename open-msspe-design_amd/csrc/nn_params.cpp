@@ -661,6 +661,16 @@ bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
     auto gv = [&](int e) -> double { return out.g[e] == W::kBig ? 0.0 : (double)out.g[e]; };
     auto hmag = [&](int e) -> double { return out.H[e] >= kHInf ? 0.0 : std::fabs((double)out.H[e]); };
     auto sneg = [&](int e) -> double { return (out.H[e] >= kHInf || out.S[e] > 0) ? 0.0 : -out.S[e]; };
+    auto hpos = [&](int e) -> double { return out.H[e] >= kHInf ? 0.0 : std::max(0.0, (double)out.H[e]); };
+    double hp = 0, hpmm = 0, hpen = 0;   // positive enthalpy per base spent / per mismatch / per end
+    for (int e = W::kWC; e < W::kWC + 16; ++e) hp = std::max(hp, hpos(e) / 2.0);
+    for (int e = W::kTSc; e < W::kZero; ++e) hpmm = std::max(hpmm, hpos(e));
+    for (int sz = 2; sz <= W::kMaxSz; ++sz)
+        for (int po = 0; po < 64; ++po) hp = std::max(hp, (hpos(W::kNB + (sz - 2) * 64 + po) + hpmm) / (sz + 2));
+    for (int ac = 0; ac < 4; ++ac)
+        for (int sz = 1; sz <= W::kMaxSz; ++sz)
+            for (int ap = 0; ap < 4; ++ap) hp = std::max(hp, hpos(W::kBU + ac * W::kBUStride + sz * 4 + ap) / (sz + 2));
+    for (int e = W::kEndL; e < W::kWC; ++e) hpen = std::max(hpen, hpos(e));
     double gneg = 0, gpos_wc = 0, hb = 0, sb = 0, gmm_lo = 0, hmm = 0, smm = 0, gen = 0, hen = 0, sen = 0;
     for (int e = W::kWC; e < W::kWC + 16; ++e) {
         gneg = std::max(gneg, -gv(e) / 2.0);
@@ -705,13 +715,18 @@ bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
         cand_hi += x_hi + y_hi;
     }
     if (std::getenv("MSSPE_DEBUG_BOUNDS"))
+        std::fprintf(stderr, "split bounds: hp %g hpmm %g hpen %g\n", hp, hpmm, hpen),
         std::fprintf(stderr, "split bounds: ok %d gneg %g gpos_wc %g hb %g sb %g gmm_lo %g gen %g hen %g cand_hi %g\n",
                      (int)ok, gneg, gpos_wc, hb, sb, gmm_lo, gen, hen, cand_hi);
+    // enthalpy H / 10 is kept in 16 unsigned bits with a bias: mostly negative values
+    constexpr int kHBias = 37500;   // stock tables: -368,000 .. +255,000 cal/mol for 32-mers
+    out.h_bias = kHBias;
     int max_k = 0;
     for (int k = 32; k >= 2 && ok; --k) {
         const bool fits = 2.0 * k * gneg + 2.0 * gen + gmm_lo < (double)W::kReach &&     // int32 sums, low side
                           2.0 * gen + k * gpos_wc + cand_hi < (double)W::kReach &&         // ... high side
-                          2.0 * k * hb + 2.0 * hen + hmm + 200.0 < 327000.0 &&      // H / 10 in 16 bits
+                          2.0 * k * hb + 2.0 * hen + hmm + 200.0 < 10.0 * kHBias &&                 // H / 10 + bias in 16 bits: low side
+                          2.0 * k * hp + 2.0 * hpen + hpmm + 200.0 < 10.0 * (65000 - kHBias) &&  // ... high side
                           2.0 * k * sb + 2.0 * sen + smm + 6.0 < 2400.0;            // MinEntropyCutoff (-2500) out of reach
         if (fits) {
             max_k = k;

@@ -1,5 +1,5 @@
 // split_tables.hpp -- tables of the exact-integer all-pairs kernel for LONG oligos
-// (thal_pairs_split.hip: 17 .. 32 bases, 5-bit cell coordinates, a pair's DP table split over
+// (thal_pairs_split.hip: 15 .. 32 bases, 5-bit cell coordinates, a pair's DP table split over
 // several lanes).
 //
 // Same exactness argument as IntTables (fast_tables.hpp): every table entropy is a multiple of
@@ -55,6 +55,7 @@ struct SplitTables {
     int32_t X[kXCount];
     int32_t usable;          // 0: the preconditions do not hold, use the generic kernel
     int32_t max_k;           // longest oligo the range checks cover (0 if unusable)
+    int32_t h_bias;          // a cell keeps H / 10 + h_bias in 16 unsigned bits
     int32_t f64_max_k;       // longest oligo for which the S / H planes alone are exact for an f64 DP
                              // (thal_pairs_wave.hip): integral enthalpies, MinEntropyCutoff out of reach
 };

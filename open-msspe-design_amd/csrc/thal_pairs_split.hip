@@ -1,14 +1,14 @@
-// thal_pairs_split.hip -- all-pairs cross-dimer kernel for LONG oligos (17 .. 32 bases): the
+// thal_pairs_split.hip -- all-pairs cross-dimer kernel for LONG oligos (15 .. 32 bases): the
 // exact-integer DP of thal_pairs_int.hip with 5-bit cell coordinates and the DP table of one pair
 // SPLIT over Q lanes.
 //
 // Same job and outputs as thal_pairs_int.hip (the reference's "format N^2 lines -> ntthal -> parse"
-// loop, /root/reference/od-msspe/src/delta_g.rs:61-153, for --kmer-size above 16; Primer3 2.6.1
+// loop, /root/reference/od-msspe/src/delta_g.rs:61-153, for --kmer-size 15 and above; Primer3 2.6.1
 // thal() restated from SURVEY.md Appendix C.3).  A pair of k-mers has about k^2 / 4 complementary
-// cells (100 at k = 20, 196 at k = 28): too many for one lane's registers.  Here Q = 2 or 4
+// cells (100 at k = 20, 196 at k = 28): too many for one lane's registers.  Here Q = 2, 4 or 8
 // neighbouring lanes share one pair:
 //   * cell number c (row-major order of the complementary cells) lives in lane c % Q, register slot
-//     c / Q, as (G, W): G = exact 2000 * dG, W = h << 16 | po << 10 | im1 << 5 | jm1;
+//     c / Q, as (G, W): G = exact 2000 * dG, W = (H / 10 + bias) << 16 | po << 10 | im1 << 5 | jm1;
 //   * all Q lanes enumerate the cells together; for cell c each lane tries its own earlier slots
 //     as predecessors (compile-time register numbers, split_tables.hpp: two LDS gathers per try),
 //     then the Q partial minima, tie flags and the (i-1, j-1) neighbour are merged with DPP
@@ -45,6 +45,7 @@ struct SharedS {
     int H[W_::kCount];
     int g[W_::kCount];
     double cq[100];                                   // 620300 * (init_S + rS + RC) per right-end context
+    int h_bias10;                                     // 10 * bias of the enthalpy field of the packed words
     unsigned short pred[kLaneSlots][kThreadsS];       // predecessor coordinates of the lane's slots
     unsigned short path[kPathMaxS][kThreadsS];        // po << 10 | im1 << 5 | jm1 of the path cells
 };
@@ -145,8 +146,10 @@ __device__ __forceinline__ void scan_s(const v32i Ga, const v32i Wa, const v32i 
 template <int MASK>
 __device__ __forceinline__ int lane_xor(int v)
 {
-    static_assert(MASK == 1 || MASK == 2, "quad permutes only");
-    return __builtin_amdgcn_mov_dpp(v, MASK == 1 ? 0xB1 : 0x4E, 0xf, 0xf, false);
+    static_assert(MASK == 1 || MASK == 2 || MASK == 4, "quad permutes and the half-row mirror");
+    // MASK 4: row_half_mirror pairs lane i with lane 7 - i of its group of eight, which merges the two
+    // quads just as well as i ^ 4 would (both already agree within themselves)
+    return __builtin_amdgcn_mov_dpp(v, MASK == 1 ? 0xB1 : (MASK == 2 ? 0x4E : 0x141), 0xf, 0xf, false);
 }
 
 // tie: 0 = one candidate holds the minimum, 1 = two (b.W, b.W2), 2 = more
@@ -205,6 +208,7 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
 {
     const int lane = threadIdx.x & 63, ql = lane & (Q - 1);
     v32i Ga = 0, Wa = kEmptyS, Gb = 0, Wb = kEmptyS;
+    const int hb10 = sh.h_bias10;   // H of a packed word = (W >> 16, unsigned) * 10 - hb10
     int defer = 0;
     unsigned long long Rrem = rowmask, mrem = 0;
     int im1 = 0, jm1 = 0;
@@ -252,7 +256,7 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
         if (stHave) {
             const int rH = sh.H[b.idxR];
             const double cq = sh.cq[b.idxR - W_::kEndR];
-            const int H1 = (stk.W >> 16) * 10 + sh.H[b.wc];
+            const int H1 = (int)((unsigned)stk.W >> 16) * 10 - hb10 + sh.H[b.wc];
             const int G1 = stk.G + sh.g[b.wc];
             const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
             const double B0 = (double)(2000 * H0 - G0) + cq, B1 = (double)(2000 * H1 - G1) + cq;
@@ -268,14 +272,14 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
         if (best.G <= G0) {
             const LoopIx g = loop_indices(b, best.W & 0xffff);
-            const int Hw = sh.H[g.lx] + sh.H[g.y] + (best.W >> 16) * 10;
+            const int Hw = sh.H[g.lx] + sh.H[g.y] + (int)((unsigned)best.W >> 16) * 10 - hb10;
             const unsigned long long my_bit = ((slot < n_cells) & ((slot & (Q - 1)) == ql)) ? (1ull << (slot / Q)) : 0ull;
             if (best.G < G0) {
                 // two loop candidates with one value: if their enthalpies agree as well the cell's
                 // value is the same either way and only a path through this cell is ambiguous
                 if (tie == 1) {
                     const LoopIx g2 = loop_indices(b, best.W2 & 0xffff);
-                    const int Hw2 = sh.H[g2.lx] + sh.H[g2.y] + (best.W2 >> 16) * 10;
+                    const int Hw2 = sh.H[g2.lx] + sh.H[g2.y] + (int)((unsigned)best.W2 >> 16) * 10 - hb10;
                     if (Hw2 == Hw) softTie |= my_bit;
                     else flags |= kDeferLoopTie;
                 } else if (tie > 1) {
@@ -291,7 +295,7 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
                 flags |= kDeferLoopEq;
             }
         }
-        const int Wcell = ((H0 / 10) << 16) | (b.po_c << 10) | (im1 << 5) | jm1;
+        const int Wcell = (int)((unsigned)((H0 + hb10) / 10) << 16) | (b.po_c << 10) | (im1 << 5) | jm1;
         const bool in = slot < n_cells;
         defer |= in ? flags : 0;
         // ---- terminal pick (strict minimum of dG incl. the right end term, first in slot order)
@@ -389,7 +393,7 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
             }
         }
         // the replayed enthalpy must be the tracked one; anything else is handed on
-        dpath |= (!out.none & (H != (endW >> 16) * 10) & ((pass == 0) | second)) ? kDeferReplay : 0;
+        dpath |= (!out.none & (H != (int)((unsigned)endW >> 16) * 10 - hb10) & ((pass == 0) | second)) ? kDeferReplay : 0;
         {
             // thal.c thal(): the nudged dG the terminal pick compares
             const CellS b = cell_s(q, (endW >> 5) & 31, endW & 31);
@@ -460,6 +464,7 @@ __device__ __forceinline__ void load_tables_s(SharedS &sh, const SplitArgs &a)
     }
     for (int e = threadIdx.x; e < 100; e += kThreadsS)
         sh.cq[e] = 620300.0 * ((a.c.init_S + a.st->S[W_::kEndR + e]) + a.c.RC);
+    if (threadIdx.x == 0) sh.h_bias10 = a.st->h_bias * 10;
     __syncthreads();
 }
 
@@ -540,8 +545,9 @@ int pairs_split_lanes(int k)
     if (const char *e = std::getenv("MSSPE_SPLIT_LANES")) {   // experiment switch
         if (e[0] == '2') return 2;
         if (e[0] == '4') return 4;
+        if (e[0] == '8') return 8;
     }
-    return k <= 20 ? 2 : 4;
+    return k <= 20 ? 2 : (k <= 28 ? 4 : 8);
 }
 
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
@@ -568,7 +574,8 @@ hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, un
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L ? tiles : 256L);   // one persistent block per CU (about 150 KB of LDS)
     if (Q == 2) hipLaunchKernelGGL(k_pairs_split<2>, dim3(grid), dim3(kThreadsS), 0, stream, x);
-    else hipLaunchKernelGGL(k_pairs_split<4>, dim3(grid), dim3(kThreadsS), 0, stream, x);
+    else if (Q == 4) hipLaunchKernelGGL(k_pairs_split<4>, dim3(grid), dim3(kThreadsS), 0, stream, x);
+    else hipLaunchKernelGGL(k_pairs_split<8>, dim3(grid), dim3(kThreadsS), 0, stream, x);
     return hipGetLastError();
 }
 

@@ -79,9 +79,9 @@ def test_edge_pools(eng, m, oracle, oracle_tables):
 
 @pytest.mark.parametrize("k", [6, 8, 12, 16, 17, 20, 21, 24, 27, 28, 29, 32])
 def test_other_oligo_lengths(eng, m, oracle, oracle_tables, k):
-    """k <= 16: register-table kernels; 17 .. 28: the table split over 2 or 4 lanes
-    (thal_pairs_split.hip); longer: the generic kernel."""
-    pool = m.synth.pool_strings(m.synth.random_pool(24 if k <= 16 else (40 if k <= 28 else 10), k, seed=100 + k))
+    """k <= 14: register-table kernels; 15 .. 32: the table split over 2, 4 or 8 lanes
+    (thal_pairs_split.hip) with the one-wave-per-pair f64 kernel behind it (thal_pairs_wave.hip)."""
+    pool = m.synth.pool_strings(m.synth.random_pool(24 if k <= 16 else 40, k, seed=100 + k))
     if k % 2 == 0:   # both-self-complementary pairs use the symmetric concentration term
         half = pool[0][:k // 2]
         pal = half + oracle.reverse_complement(half)
@@ -327,9 +327,9 @@ def test_parameter_files_from_a_path(m, oracle, tmp_path, mode, k):
         e.close()
 
 
-@pytest.mark.parametrize("k,max_loop", [(18, 30), (20, 30), (22, 6), (26, 30)])
+@pytest.mark.parametrize("k,max_loop", [(18, 30), (20, 30), (22, 6), (26, 30), (32, 30)])
 def test_long_oligo_stage_equals_generic_kernel(m, oracle, oracle_tables, monkeypatch, k, max_loop):
-    """The split-table integer stage (17 .. 28 bases) against the dense f64 kernel on a pool the
+    """The split-table integer stage (15 .. 32 bases) against the dense f64 kernel on a pool the
     oracle would need minutes for: same decisions, same counts; a sample of rows bit-exact against
     the oracle; a loop-size limit below 30 is honoured (thal.c maxLoop)."""
     n = 768
