@@ -150,6 +150,8 @@ def test_cli_needs_a_gpu_for_the_pipeline(host, tmp_path):
     (["--keep-all", "true", "--max-mismatch-segments", "3"], dict(keep_all=True, max_mismatch_segments=3)),
     (["--delta-g-threshold", "-4000", "--annealing-temp", "37", "--disable-tm-stddev", "true"],
      dict(dg=-4000.0, temp=37.0, disable_tm_stddev=True)),
+    # 20-mers: stage C runs on the split-table kernel (thal_pairs_split.hip)
+    (["--kmer-size", "20", "--max-tm", "80", "--max-iterations", "60"], dict(kmer_size=20, max_tm=80.0, max_iterations=60)),
 ])
 def test_end_to_end_cli_matches_the_restated_pipeline(host, tmp_path, extra, kw):
     """Whole run (stage A -> B -> C -> vertex cover -> CSV + report) on a synthetic alignment:
