@@ -413,11 +413,13 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     const int ncols = col1 - col0;
     const int words = (ncols + 63) / 64;
     // long oligos: exact-integer kernel with a pair's table split over lanes (honours max_loop)
-    const bool split = !use_generic_only() && !use_f64_pairs() && k >= split_min_k() && k <= ce->split_max_k;
+    // (also short oligos under a loop-size limit the register-table kernels do not implement)
+    const bool split = !use_generic_only() && !use_f64_pairs() && k <= ce->split_max_k &&
+                       (k >= split_min_k() || chem->max_loop < 2 * k - 4);
     // f64, one wave per pair: behind the split kernel, and as the first stage where neither the split
     // kernel nor the register-table chain applies (29 .. 32 bases, parameter files off the grid)
     const bool wave_ok = !use_generic_only() && k <= ce->wave_max_k && std::getenv("MSSPE_NO_WAVE_KERNEL") == nullptr;
-    const bool wave_matrix = wave_ok && !split && k > pairs_fast_max_k();
+    const bool wave_matrix = wave_ok && !split && (k > pairs_fast_max_k() || chem->max_loop < 2 * k - 4);
     const bool fast = split || wave_matrix ||
                       (!use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
                        chem->max_loop >= 2 * k - 4);   // the tuned kernel has no loop-size cut-off

@@ -68,6 +68,21 @@ def test_chemistry_and_threshold_variants(eng, m, oracle, oracle_tables):
     check_pool(eng, m, oracle, oracle_tables, pool, dict(dv=1.5, dntp=0.6), -3000.0)
 
 
+def test_loop_size_limit_on_short_oligos(eng, m, oracle, oracle_tables):
+    """thal.c maxLoop below 2k - 4: the register-table kernels have no cut-off, the split-table kernel
+    (and behind it the one-wave-per-pair kernel) takes the block."""
+    pool = m.synth.pool_strings(m.synth.random_pool(120, 13, seed=9))
+    for max_loop in (0, 3, 8):
+        chem = m.Chem.ntthal()
+        chem.max_loop = max_loop
+        out = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+        _, dg, cf, tt = oracle.pool_pairs(oracle_tables, pool, oracle.ntthal_args(max_loop=max_loop), -9000.0, want_t=True)
+        np.testing.assert_array_equal(out["dg"], dg)
+        np.testing.assert_array_equal(out["tm"], tt)
+        np.testing.assert_array_equal(out["row_conflicts"], cf.sum(1).astype(np.uint32))
+    assert eng.pair_stage_stats()["deferred"] > 0      # the integer stage ran
+
+
 def test_edge_pools(eng, m, oracle, oracle_tables):
     """No-structure pairs, maximal DP tables (poly-A x poly-T: 169 cells), homopolymers, repeats."""
     pool = ["A" * 13, "T" * 13, "C" * 13, "G" * 13, "ACACACACACACA", "TGTGTGTGTGTGT",
