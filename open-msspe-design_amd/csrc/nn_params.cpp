@@ -714,10 +714,6 @@ bool build_split_tables(const PairTables &pt, int max_loop, SplitTables &out)
         for (int e = W::kTSc; e < W::kZero; ++e) y_hi = std::max(y_hi, gv(e));
         cand_hi += x_hi + y_hi;
     }
-    if (std::getenv("MSSPE_DEBUG_BOUNDS"))
-        std::fprintf(stderr, "split bounds: hp %g hpmm %g hpen %g\n", hp, hpmm, hpen),
-        std::fprintf(stderr, "split bounds: ok %d gneg %g gpos_wc %g hb %g sb %g gmm_lo %g gen %g hen %g cand_hi %g\n",
-                     (int)ok, gneg, gpos_wc, hb, sb, gmm_lo, gen, hen, cand_hi);
     // enthalpy H / 10 is kept in 16 unsigned bits with a bias: mostly negative values
     constexpr int kHBias = 37500;   // stock tables: -368,000 .. +255,000 cal/mol for 32-mers
     out.h_bias = kHBias;
