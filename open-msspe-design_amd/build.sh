@@ -23,9 +23,9 @@ echo "built $here/libmsspe_hip.so"
 # host side above the C ABI (C++17, no HIP): the reference-interface mirror, its CLI and test hooks
 cd "$here/host"
 CXX="${CXX:-g++}"
-"$CXX" -O2 -std=c++17 -fPIC -Wall -shared -o "$here/libod_msspe_host.so" od_msspe.cpp c_hooks.cpp \
+"$CXX" -O2 -std=c++17 -fPIC -Wall -pthread -shared -o "$here/libod_msspe_host.so" od_msspe.cpp c_hooks.cpp \
     -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
-"$CXX" -O2 -std=c++17 -Wall -o "$here/od-msspe-hip" main.cpp od_msspe.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
+"$CXX" -O2 -std=c++17 -Wall -pthread -o "$here/od-msspe-hip" main.cpp od_msspe.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN'
 mkdir -p "$here/bin"
 "$CXX" -O2 -std=c++17 -Wall -o "$here/bin/ntthal-hip" ntthal_shim.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN/..'
 "$CXX" -O2 -std=c++17 -Wall -o "$here/bin/primer3_core-hip" primer3_shim.cpp -L"$here" -lmsspe_hip -Wl,-rpath,'$ORIGIN/..'

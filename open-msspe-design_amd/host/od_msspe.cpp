@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 #include <unordered_set>
 
 namespace od_msspe {
@@ -146,9 +147,12 @@ Args Args::parse(int argc, const char *const *argv)
 // ---------------------------------------------------------------------------------------------
 // FASTA (main.rs:108-122; seq_io semantics: id = header up to the first space, lines joined)
 // ---------------------------------------------------------------------------------------------
-std::vector<SequenceRecord> to_records(const std::string &fasta)
+namespace {
+
+// records of the byte range [p, end): one pass; sequence bytes go through a 256-entry table
+// (upper case, U -> T).  Bytes before the first header of the range are ignored.
+std::vector<SequenceRecord> parse_fasta_range(const char *p, const char *end)
 {
-    // one pass over the buffer; sequence bytes go through a 256-entry table (upper case, U -> T)
     static const auto table = [] {
         std::array<char, 256> t{};
         for (int c = 0; c < 256; ++c) {
@@ -158,7 +162,6 @@ std::vector<SequenceRecord> to_records(const std::string &fasta)
         return t;
     }();
     std::vector<SequenceRecord> out;
-    const char *p = fasta.data(), *end = p + fasta.size();
     size_t reserve_hint = 0;
     while (p < end) {
         const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
@@ -178,6 +181,45 @@ std::vector<SequenceRecord> to_records(const std::string &fasta)
         }
         p = nl ? nl + 1 : end;
     }
+    return out;
+}
+
+}  // namespace
+
+std::vector<SequenceRecord> to_records(const std::string &fasta)
+{
+    const char *base = fasta.data(), *end = base + fasta.size();
+    // large inputs: cut at header lines and parse the pieces on the host's cores
+    const size_t n_threads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16,
+                                               fasta.size() / (8u << 20)});
+    if (n_threads < 2) return parse_fasta_range(base, end);
+    std::vector<const char *> cut{base};
+    for (size_t t = 1; t < n_threads; ++t) {
+        const char *p = base + fasta.size() / n_threads * t;
+        const char *hit = nullptr;
+        while (p < end) {   // next line that starts with '>'
+            const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
+            if (!nl || nl + 1 >= end) break;
+            if (nl[1] == '>') {
+                hit = nl + 1;
+                break;
+            }
+            p = nl + 1;
+        }
+        if (hit && hit > cut.back()) cut.push_back(hit);
+    }
+    cut.push_back(end);
+    std::vector<std::vector<SequenceRecord>> parts(cut.size() - 1);
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t + 1 < cut.size(); ++t)
+        pool.emplace_back([&, t] { parts[t] = parse_fasta_range(cut[t], cut[t + 1]); });
+    for (auto &th : pool) th.join();
+    std::vector<SequenceRecord> out;
+    size_t total = 0;
+    for (const auto &v : parts) total += v.size();
+    out.reserve(total);
+    for (auto &v : parts)
+        for (auto &r : v) out.push_back(std::move(r));
     return out;
 }
 

@@ -60,6 +60,25 @@ def test_fasta_normalisation(host):
     assert out == "seq1\tACGTNN-A\nseq2\tTTTT\n"
 
 
+def test_fasta_large_input_is_parsed_in_pieces(host):
+    """Inputs above 16 MB are cut at header lines and parsed on several host threads: same records,
+    same order, whatever the line structure (wrapped lines, CRLF, lower case, U, a header-less head)."""
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTacgtuUN-", dtype=np.uint8)
+    parts, want = ["stray line before any header\n"], []
+    for r in range(900):
+        seq = alphabet[rng.integers(0, len(alphabet), 20000 + int(rng.integers(0, 9000)))].tobytes().decode()
+        width = int(rng.integers(50, 200))
+        eol = "\r\n" if r % 7 == 0 else "\n"
+        parts.append(f">rec{r} description {r}{eol}" + eol.join(seq[i:i + width] for i in range(0, len(seq), width)) + eol)
+        want.append(f"rec{r}\t" + seq.upper().replace("U", "T"))
+    fasta = "".join(parts).encode()
+    assert len(fasta) > (16 << 20)
+    rc, out = call(host.odm_to_records, fasta, cap=len(fasta) + (1 << 20))
+    got = out.splitlines()
+    assert len(got) == 900 and got == want
+
+
 def test_vertex_cover_rules(host):
     """main.rs:754-798: most live conflicts first, ties to the lexicographically greatest primer,
     a self-conflicting primer is always removed."""
