@@ -166,11 +166,16 @@ def test_counts_and_bitmap_only_path_medium_pool(eng, m, oracle, oracle_tables):
     assert eng.last_overflow_pairs() > 0      # the overflow stages were exercised
 
 
-def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables):
-    """A rectangular block of the pair matrix (what one rank computes in the multi-GPU tiling)."""
+@pytest.mark.parametrize("k,no_split", [(13, False), (21, False), (21, True)])
+def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k, no_split):
+    """A rectangular block of the pair matrix (what one rank computes in the multi-GPU tiling); for
+    21-mers through the split-table kernel and, with that one switched off, through the matrix mode
+    of the one-wave-per-pair kernel."""
     import torch
+    if no_split:
+        monkeypatch.setenv("MSSPE_SPLIT_MIN_K", "99")
     n = 200
-    pool_ascii = m.synth.random_pool(n, 13, seed=78)
+    pool_ascii = m.synth.random_pool(n, k, seed=78)
     d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
     r0, r1, c0, c1 = 37, 150, 64, 200
     d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
@@ -178,7 +183,7 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables):
     d_bm = torch.zeros((r1 - r0, (c1 - c0 + 63) // 64), dtype=torch.int64, device="cuda")
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     try:
-        eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, m.Chem.ntthal(), -9000.0, (r0, r1), (c0, c1),
+        eng.cross_dimer_dev(d_pool.data_ptr(), n, k, m.Chem.ntthal(), -9000.0, (r0, r1), (c0, c1),
                             d_rc.data_ptr(), d_bm.data_ptr(), d_dg.data_ptr())
         torch.cuda.synchronize()
     finally:
