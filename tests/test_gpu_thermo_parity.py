@@ -92,6 +92,21 @@ def test_edge_pools(eng, m, oracle, oracle_tables):
     assert np.isfinite(out["dg"][0, 1])
 
 
+@pytest.mark.parametrize("k", [18, 24, 31])
+def test_edge_pools_long_oligos(eng, m, oracle, oracle_tables, k):
+    """Low-complexity long oligos: tables of k^2 cells (poly-A x poly-T: beyond every LDS table, dense
+    kernel), dinucleotide repeats (hundreds of exact ties), self-complementary pairs, near-duplicates."""
+    rep = lambda unit: (unit * k)[:k]
+    half = rep("ACGGT")[:k // 2]
+    pool = ["A" * k, "T" * k, "G" * k, "C" * k, rep("AC"), rep("GT"), rep("TG"), rep("AT"), rep("GC"),
+            rep("AAT"), rep("ATT"), rep("ACG"), rep("CGT"), rep("AACCGGTT"), rep("AAAACCCCGGGGTTTT"),
+            half + oracle.reverse_complement(half) + ("A" if k % 2 else ""), rep("GCGCAT"), rep("ATGCGC")]
+    pool += m.synth.pool_strings(m.synth.random_pool(6, k, seed=k))
+    pool.append(pool[-1][:-1] + ("A" if pool[-1][-1] != "A" else "C"))
+    out, _ = check_pool(eng, m, oracle, oracle_tables, pool)
+    assert np.isinf(out["dg"][0, 0]) and np.isfinite(out["dg"][0, 1])
+
+
 @pytest.mark.parametrize("k", [6, 8, 12, 16, 17, 20, 21, 24, 27, 28, 29, 32])
 def test_other_oligo_lengths(eng, m, oracle, oracle_tables, k):
     """k <= 14: register-table kernels; 15 .. 32: the table split over 2, 4 or 8 lanes
