@@ -26,8 +26,8 @@ namespace msspe {
 
 namespace {
 
-constexpr int kWaveCells = 448;      // cells per pair in LDS (random 32-mers: 256 +- 14)
-constexpr int kWavesPerBlock = 4;
+constexpr int kWaveCells = 384;      // cells per pair in LDS (random 32-mers: 256 +- 14); two 8-wave blocks per CU
+constexpr int kWavesPerBlock = 8;
 constexpr int kThreadsW = 64 * kWavesPerBlock;
 
 struct SharedWv {
@@ -343,7 +343,7 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
     x.ovf_count = a.overflow_count;
     x.ovf_cap = a.overflow_cap;
     if (!in_list && ((long)(a.row1 - a.row0) * (long)(a.col1 - a.col0) <= 0)) return hipSuccess;
-    hipLaunchKernelGGL(k_pairs_wave, dim3(256 * 3), dim3(kThreadsW), 0, stream, x);
+    hipLaunchKernelGGL(k_pairs_wave, dim3(256 * 2), dim3(kThreadsW), 0, stream, x);
     return hipGetLastError();
 }
 
