@@ -43,7 +43,7 @@ struct ChemEntry {
 };
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
-constexpr long kListCapMin = 1L << 27;       // hand-over list entries: one launch can never overrun it
+constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows with the call up to kListCapMax): one launch can never overrun it
 constexpr long kListCapMax = 1L << 30;       // 8 GB per list: 16 launches between flushes (288 GB HBM)
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
@@ -812,6 +812,10 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     if (d_tm || d_gc)
         HIP_TRY(ctx, launch_oligo_tm(d_pool, n, k, chem->dna_conc, chem->mv, chem->dv, chem->dntp,
                                      d_tm, d_gc, ctx->stream));
+    // SELF_ANY / SELF_END: one wave per oligo (thal_pairs_wave.hip); the dense kernel, one lane per
+    // oligo, only takes what that kernel leaves (self-complementary oligos, oversized tables)
+    const bool wave_ok = !use_generic_only() && k <= ce->wave_max_k && std::getenv("MSSPE_NO_WAVE_KERNEL") == nullptr;
+    if (wave_ok && (rc = ensure_overflow(ctx, n))) return rc;
     for (int pass = 0; pass < 2; ++pass) {
         double *dst = pass == 0 ? d_self_any : d_self_end;
         if (!dst) continue;
@@ -829,8 +833,16 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         g.wsS = ctx->wsS;
         g.wsH = ctx->wsH;
         g.ws_lanes = kGenericLanes;
+        if (wave_ok) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
+            HIP_TRY(ctx, launch_self_wave(ce->d_st, ce->c[0], d_pool, k, 0, n, pass == 1, dst, ctx->ovf_list,
+                                          ctx->ovf_count, (uint32_t)ctx->list_cap, ctx->stream));
+            g.list = ctx->ovf_list;
+            g.list_count = ctx->ovf_count;
+        }
         HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
     }
+    if (wave_ok) HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
     if (d_hairpin) {
         HairpinArgs h;
         h.tb = ctx->d_tb;

@@ -106,6 +106,11 @@ int pairs_split_lanes(int k);
 // tables) are appended to a.overflow_list for launch_dimer_generic.
 hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, const uint2 *in_list,
                              const uint32_t *in_count, hipStream_t stream);
+// Stage B on the same kernel: thal ANY / END1 of every oligo of [row0, row1) with itself, self_t[row] =
+// max(0, t); what it does not take is appended to list as (row, row).
+hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
+                            int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
+                            uint32_t list_cap, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();

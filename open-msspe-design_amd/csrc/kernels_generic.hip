@@ -34,11 +34,11 @@ __global__ void __launch_bounds__(256) k_dimer_generic(GenericDimerArgs a)
     }
     for (long w = (long)lane; w < n_work; w += (long)a.ws_lanes) {
         int row, col;
-        if (a.self_mode) {
-            row = col = (int)w;
-        } else if (a.list) {
+        if (a.list) {
             row = (int)(a.list[w].x & 0x7fffffffu);   // bit 31: mark of the integer stage
             col = (int)a.list[w].y;
+        } else if (a.self_mode) {
+            row = col = (int)w;
         } else {
             row = a.sinks.row0 + (int)(w / a.sinks.ncols);
             col = a.sinks.col0 + (int)(w % a.sinks.ncols);
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_dimer_generic(GenericDimerArgs a)
             det->no_structure = o.none;
             det->n_pairs = o.n_pairs;
         } else if (a.self_mode) {
-            a.self_t[w] = (o.none || o.t < 0.0) ? 0.0 : o.t;   // libprimer3 align_thermod()
+            a.self_t[row] = (o.none || o.t < 0.0) ? 0.0 : o.t;   // libprimer3 align_thermod()
         } else {
             sink_pair(a.sinks, ctx.c, row, col, o);
         }

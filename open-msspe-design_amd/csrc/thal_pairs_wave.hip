@@ -20,6 +20,8 @@
 //   * terminal pick and thal.c's value-matching traceback are the same parallel sweep + reduction.
 // Pairs of two self-complementary oligos (other RC constant) and pairs with more cells than the LDS
 // table holds go to the next list, for the dense kernel.
+#include <cstring>
+
 #include "split_core.hpp"
 
 namespace msspe {
@@ -51,6 +53,10 @@ struct WaveArgs {
     uint2 *ovf_list;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
+    // self mode (stage B, libprimer3 align_thermod of an oligo with itself): work item w = pair
+    // (row0 + w, row0 + w), result self_t[row] = max(0, t); end1: thal END1 instead of ANY
+    double *self_t;
+    int end1;
 };
 
 // all lanes of the wave end up with the same value
@@ -106,7 +112,7 @@ __device__ __forceinline__ CandW candidate(const SharedWv &sh, const CellS &b, i
 
 // thal ANY for one pair, computed by the whole wave.  Returns false when the pair does not fit.
 __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint64_t pa, uint64_t pb, int k,
-                              WaveResult &out)
+                              bool end1, WaveResult &out)
 {
     const int lane = threadIdx.x & 63;
     double *cS = sh.cS[wave];
@@ -207,7 +213,8 @@ __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint6
         const CellS b = cell_s(q, (Wp >> 5) & 31, Wp & 31);
         const double rSn = sh.S[b.idxR] + kTiny, rHn = (double)sh.H[b.idxR] + kTiny;
         const double Gt = (((double)cH[p] + rHn) + K.init_H) - kT37 * ((cS[p] + rSn) + K.init_S);
-        const bool pick = Gt < pickG;
+        // thal END1: only structures that close on the 3' base of oligo 1 (the last row)
+        const bool pick = (Gt < pickG) & (!end1 | (((Wp >> 5) & 31) == k - 1));
         pickG = pick ? Gt : pickG;
         pickSlot = pick ? p : pickSlot;
     }
@@ -216,9 +223,14 @@ __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint6
         pickG = __shfl(pickG, who);
         pickSlot = __shfl(pickSlot, who);
     }
-    if (!(pickG < INFINITY)) {   // no cell has a finite value: thal() reports no structure
-        out.none = true;
-        return true;
+    if (!(pickG < INFINITY)) {
+        // no candidate: thal() falls back to cell (1, 1) and reports no structure unless that cell
+        // is a base pair (only reachable in END1 mode, where the last row may hold no cell)
+        if ((cW[0] & 0x3ff) != 0) {
+            out.none = true;
+            return true;
+        }
+        pickSlot = 0;
     }
     const double pickS = cS[pickSlot];
     const int pickH = cH[pickSlot];
@@ -281,11 +293,14 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = a.col1 - a.col0;
-    const long n_work = a.in_list ? (long)min(*a.in_count, a.in_cap) : (long)(a.row1 - a.row0) * ncols;
+    const long n_work = a.self_t ? (long)(a.row1 - a.row0)
+                                 : (a.in_list ? (long)min(*a.in_count, a.in_cap) : (long)(a.row1 - a.row0) * ncols);
     const long stride = (long)gridDim.x * kWavesPerBlock;
     for (long w = (long)blockIdx.x * kWavesPerBlock + wave; w < n_work; w += stride) {
         int row, col;
-        if (a.in_list) {
+        if (a.self_t) {
+            row = col = a.row0 + (int)w;
+        } else if (a.in_list) {
             const uint2 pr = a.in_list[w];
             row = (int)(pr.x & 0x7fffffffu);
             col = (int)pr.y;
@@ -300,11 +315,15 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
         r.conflict = false;
         r.dG = INFINITY;
         r.t = 0.0;
-        const bool fits = !sym && run_pair_wave(sh, wave, a.c, pa, pb, a.k, r);
+        const bool fits = !sym && run_pair_wave(sh, wave, a.c, pa, pb, a.k, a.end1 != 0, r);
         if (lane != 0) continue;
         if (!fits) {
             const uint32_t at = atomicAdd(a.ovf_count, 1u);
             if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
+            continue;
+        }
+        if (a.self_t) {
+            a.self_t[row] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
             continue;
         }
         const size_t orow = (size_t)(row - a.sinks.row0);
@@ -342,8 +361,38 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
     x.ovf_list = a.overflow_list;
     x.ovf_count = a.overflow_count;
     x.ovf_cap = a.overflow_cap;
+    x.self_t = nullptr;
+    x.end1 = 0;
     if (!in_list && ((long)(a.row1 - a.row0) * (long)(a.col1 - a.col0) <= 0)) return hipSuccess;
     hipLaunchKernelGGL(k_pairs_wave, dim3(256 * 2), dim3(kThreadsW), 0, stream, x);
+    return hipGetLastError();
+}
+
+// Stage B: thal ANY (end1 = false) or END1 of every oligo of [row0, row1) with itself, self_t[row] =
+// max(0, t).  Oligos it does not take (self-complementary ones, oversized tables) are appended to
+// list as (row, row) for launch_dimer_generic.
+hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
+                            int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
+                            uint32_t list_cap, hipStream_t stream)
+{
+    WaveArgs x;
+    std::memset(&x, 0, sizeof x);
+    x.st = st;
+    x.c = c;
+    x.pool = pool;
+    x.k = k;
+    x.row0 = row0;
+    x.row1 = row1;
+    x.col0 = 0;
+    x.col1 = 1;
+    x.ovf_list = list;
+    x.ovf_count = list_count;
+    x.ovf_cap = list_cap;
+    x.self_t = self_t;
+    x.end1 = end1 ? 1 : 0;
+    if (row1 <= row0) return hipSuccess;
+    const int blocks = (row1 - row0 + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(k_pairs_wave, dim3(blocks < 512 ? blocks : 512), dim3(kThreadsW), 0, stream, x);
     return hipGetLastError();
 }
 

@@ -123,7 +123,10 @@ def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
     """primer3_core view (od-msspe/src/primer.rs:143-166): Tm, GC%, SELF_ANY/END, HAIRPIN."""
     pool = m.synth.pool_strings(m.synth.random_pool(300, 13, seed=9))
     pool += ["AGCCCGTGTAAAC", "ACGTGAAAACGTA", "GCGCTTTTGCGCA", "GGGGCCCTTTGGG", "ATATATATATATA",
-             "GGGGGGGCCCCCC", "AAAAAAAAAAAAA", "CCCGGGAAACCCG"]
+             "GGGGGGGCCCCCC", "AAAAAAAAAAAAA", "CCCGGGAAACCCG",
+             # END1 corner cases: no partner for the 3' base anywhere (last row of the DP empty), with
+             # and without other base pairs; a 3' base whose only partner is the 5' base
+             "AAAAAAAAAAAAC", "GGGGGGGGGGGCA", "TTTTTTTTTTTTA", "TAAAAAAAAAAAA", "CACACACACACAG"]
     got = eng.oligo_stats(pool)
     ref = oracle.check_primers(oracle_tables, pool)
     for a, b in (("tm", "tm"), ("gc", "gc"), ("self_any", "self_any_th"),
@@ -134,7 +137,7 @@ def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
     assert m.round_fixed_f32(got["tm"][i], 3) == np.float32(g["tm"])
     assert m.round_fixed_f32(got["gc"][i], 3) == np.float32(g["gc"])
     assert got["self_any"][i] == 0.0 and got["self_end"][i] == 0.0 and got["hairpin"][i] == 0.0
-    assert (got["hairpin"] > 0).sum() >= 3
+    assert (got["hairpin"] > 0).sum() >= 3 and (got["self_any"] > 0).sum() >= 3
 
 
 def test_oligo_stats_longer_oligos(eng, m, oracle, oracle_tables):
