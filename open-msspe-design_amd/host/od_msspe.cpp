@@ -472,24 +472,32 @@ std::set<std::string> vertex_cover(const std::vector<std::string> &primers, cons
             }
     }
     // main.rs:776-798: repeatedly delete the primer with most live conflicts; ties go to the
-    // lexicographically greatest string
+    // lexicographically greatest string.  Same rule on integer ids (the map iterates in
+    // lexicographic order, so a node's id is its rank) with live degrees kept up to date.
+    std::vector<const std::string *> name;
+    std::map<std::string, int> id;
+    for (const auto &kv : conflicts) {
+        id.emplace(kv.first, (int)name.size());
+        name.push_back(&kv.first);
+    }
+    const int n = (int)name.size();
+    std::vector<std::vector<int>> adj((size_t)n);
+    std::vector<int> live((size_t)n, 0);
+    std::vector<char> gone((size_t)n, 0);
+    for (const auto &kv : conflicts) {
+        auto &list = adj[(size_t)id[kv.first]];
+        for (const auto &nb : kv.second) list.push_back(id[nb]);
+        live[(size_t)id[kv.first]] = (int)list.size();
+    }
     std::set<std::string> deleted;
     for (;;) {
-        const std::string *worst = nullptr;
-        size_t worst_count = 0;
-        for (const auto &kv : conflicts) {
-            if (deleted.count(kv.first)) continue;
-            size_t active = 0;
-            for (const auto &nb : kv.second)
-                if (!deleted.count(nb)) ++active;
-            if (active == 0) continue;
-            if (!worst || active > worst_count || (active == worst_count && kv.first > *worst)) {
-                worst = &kv.first;
-                worst_count = active;
-            }
-        }
-        if (!worst) break;
-        deleted.insert(*worst);
+        int worst = -1;
+        for (int v = 0; v < n; ++v)   // ascending rank: ">=" keeps the greatest string among equals
+            if (!gone[(size_t)v] && live[(size_t)v] > 0 && (worst < 0 || live[(size_t)v] >= live[(size_t)worst])) worst = v;
+        if (worst < 0) break;
+        gone[(size_t)worst] = 1;
+        deleted.insert(*name[(size_t)worst]);
+        for (int nb : adj[(size_t)worst]) --live[(size_t)nb];   // conflicts are symmetric
     }
     return deleted;
 }
