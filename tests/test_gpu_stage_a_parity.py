@@ -72,6 +72,27 @@ def test_small_parameters_and_ties(eng, m, oracle):
     run_both(eng, m, oracle, seqs, seg=60, stride=30, win=30, k=8, iters=1000, mm=4)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_mixed_tie_rates(eng, m, oracle, seed):
+    """Alignments whose tie rate ranges from rare to constant: the greedy loop switches between its
+    fast iterations (single word at the maximum), single full iterations (a lone tie) and batches
+    of full iterations, at batch boundaries and in mid-batch, and must emit the reference's winners
+    whatever the schedule; with and without a cap on the iterations."""
+    rng = np.random.default_rng(100 + seed)
+    rows, length = int(rng.integers(12, 90)), int(rng.integers(1500, 5000))
+    rate = [0.002, 0.01, 0.03, 0.08, 0.15, 0.3, 0.01, 0.05][seed]
+    anc = rng.integers(0, 4, length)
+    seqs = []
+    for _ in range(rows):
+        row = anc.copy()
+        mut = rng.random(length) < rate
+        row[mut] = rng.integers(0, 4, int(mut.sum()))
+        seqs.append("".join("ACGT"[x] for x in row))
+    k = int(rng.choice([6, 9, 13]))
+    run_both(eng, m, oracle, seqs, seg=200, stride=100, win=40, k=k, iters=1000, mm=int(rng.integers(1, 4)))
+    run_both(eng, m, oracle, seqs, seg=200, stride=100, win=40, k=k, iters=int(rng.integers(1, 70)), mm=1)
+
+
 def test_long_posting_lists_and_ties(eng, m, oracle):
     """700 near-identical rows: posting lists of thousands of segments spread over many partitions
     (k = 3) tie at the same frequency, so the block-per-word scoring kernel, its ordered path and
