@@ -20,8 +20,12 @@ __device__ __forceinline__ int composition_bin(uint64_t w, int k)
 {
     int cnt[4] = {0, 0, 0, 0};
     for (int p = 0; p < k; ++p) cnt[(w >> (2 * p)) & 3]++;
-    // order bins so that neighbours differ little: T-rich ... A-rich along the major axis
-    return (cnt[0] * 33 + cnt[1]) * 33 + cnt[2];
+    // order bins so that neighbours differ little: T-rich ... A-rich along the major axis, the
+    // minor axes walked back and forth (boustrophedon), so that consecutive bins always differ by
+    // one base and a wave that straddles a bin boundary still holds near-equal table sizes
+    const int c1 = (cnt[0] & 1) ? 32 - cnt[1] : cnt[1];
+    const int c2 = ((cnt[0] + c1) & 1) ? 32 - cnt[2] : cnt[2];
+    return (cnt[0] * 33 + c1) * 33 + c2;
 }
 
 __global__ void k_hist(const uint64_t *pool, int col0, int ncols, int k, uint32_t *bins)

@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(THREADS) k_pairs_int(IntArgs a)
 // table size (64 slots), with the two-cell terminal pick settled by a second walk; what meets
 // another kind of tie or still does not fit goes to the output list.  Batches of kListBatchI x 512 entries are
 // counting-sorted in LDS (the predecessor rows double as scratch) and written back in place.
-constexpr int kListBatchI = 4;
+constexpr int kListBatchI = 7;
 __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
 {
     typedef SharedI<kSlotsList, kThreadsI, IntTables::kRows> SH;
