@@ -14,6 +14,11 @@
 #include <memory>
 #include <sstream>
 #include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_set>
 
 namespace od_msspe {
@@ -189,14 +194,19 @@ std::vector<SequenceRecord> parse_fasta_range(const char *p, const char *end)
 
 std::vector<SequenceRecord> to_records(const std::string &fasta)
 {
-    const char *base = fasta.data(), *end = base + fasta.size();
+    return to_records(fasta.data(), fasta.size());
+}
+
+std::vector<SequenceRecord> to_records(const char *base, size_t size)
+{
+    const char *end = base + size;
     // large inputs: cut at header lines and parse the pieces on the host's cores
     const size_t n_threads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16,
-                                               fasta.size() / (8u << 20)});
+                                               size / (8u << 20)});
     if (n_threads < 2) return parse_fasta_range(base, end);
     std::vector<const char *> cut{base};
     for (size_t t = 1; t < n_threads; ++t) {
-        const char *p = base + fasta.size() / n_threads * t;
+        const char *p = base + size / n_threads * t;
         const char *hit = nullptr;
         while (p < end) {   // next line that starts with '>'
             const char *nl = static_cast<const char *>(std::memchr(p, '\n', (size_t)(end - p)));
@@ -648,18 +658,30 @@ int run(const Args &args, std::string &stdout_text)
     if (args.do_align == "true")
         throw std::runtime_error("--do-align true: MAFFT is a host-side pre-step outside this engine; "
                                  "align the input first and pass --do-align false");
-    std::string fasta;
+    std::vector<SequenceRecord> records;
     {
-        std::ifstream f(args.input, std::ios::binary | std::ios::ate);
-        if (!f) throw std::runtime_error("cannot read " + args.input);
-        const std::streamoff size = f.tellg();
-        f.seekg(0);
-        fasta.resize((size_t)std::max<std::streamoff>(size, 0));
-        if (size > 0) f.read(&fasta[0], size);
-        if (!f) throw std::runtime_error("cannot read " + args.input);
+        // regular files are mapped and parsed in place (no copy of a multi-hundred-MB input);
+        // anything else (pipes) is read through a stream
+        const int fd = ::open(args.input.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot read " + args.input);
+        struct stat st;
+        void *map = MAP_FAILED;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0)
+            map = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (map != MAP_FAILED) {
+            (void)::madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+            records = to_records(static_cast<const char *>(map), (size_t)st.st_size);
+            (void)::munmap(map, (size_t)st.st_size);
+            ::close(fd);
+        } else {
+            ::close(fd);
+            std::ifstream f(args.input, std::ios::binary);
+            if (!f) throw std::runtime_error("cannot read " + args.input);
+            std::ostringstream all;
+            all << f.rdbuf();
+            records = to_records(all.str());
+        }
     }
-    const auto records = to_records(fasta);
-    std::string().swap(fasta);
     if (records.empty()) throw Panic("No sequences found in the input file");
     timer.lap("read + to_records");
 

@@ -74,6 +74,7 @@ struct SequenceRecord {   // main.rs:21-24
     std::string name, sequence;
 };
 std::vector<SequenceRecord> to_records(const std::string &fasta);   // main.rs:108-122
+std::vector<SequenceRecord> to_records(const char *fasta, size_t size);
 std::string reverse_complement(const std::string &s);               // main.rs:148-161
 
 struct KmerFrequency {   // main.rs:47-51
