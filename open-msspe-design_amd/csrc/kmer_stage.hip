@@ -20,6 +20,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -678,8 +679,8 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     // both kinds of iteration captured once: [0] fast (three launches), [1] full (five)
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t exec[2] = {nullptr, nullptr};
-    bool use_graph = true;
-    {
+    bool use_graph = std::getenv("MSSPE_NO_GRAPH") == nullptr;   // testing aid: plain launches
+    if (use_graph) {
         // capture on a private stream so that the caller's stream may be of any kind
         hipStream_t cs = nullptr;
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) use_graph = false;
