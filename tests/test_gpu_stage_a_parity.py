@@ -93,6 +93,13 @@ def test_mixed_tie_rates(eng, m, oracle, seed):
     run_both(eng, m, oracle, seqs, seg=200, stride=100, win=40, k=k, iters=int(rng.integers(1, 70)), mm=1)
 
 
+def test_plain_launches_instead_of_graph_replays(eng, m, oracle, monkeypatch):
+    """The greedy loop's fallback when hipGraph capture is not available."""
+    monkeypatch.setenv("MSSPE_NO_GRAPH", "1")
+    seqs = [bytes(r).decode() for r in m.synth.aligned_genomes(30, 4000)]
+    run_both(eng, m, oracle, seqs, mm=2)
+
+
 def test_long_posting_lists_and_ties(eng, m, oracle):
     """700 near-identical rows: posting lists of thousands of segments spread over many partitions
     (k = 3) tie at the same frequency, so the block-per-word scoring kernel, its ordered path and
