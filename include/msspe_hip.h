@@ -213,6 +213,11 @@ int msspe_segment_coverage_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq,
  * context's device once and use the *_dev entry points on it (the alignment is read by both
  * directions of stage A and by the coverage report). */
 int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **device_out);
+/* The same for a matrix given as separate rows (an alignment held as one string per record): row r is
+ * rows[r][0 .. row_bytes[r]) followed by `pad` bytes up to row_len; staged through pinned buffers, the
+ * host never builds the rectangular copy. */
+int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                          size_t row_len, int pad, void **device_out);
 int msspe_device_free(msspe_ctx *ctx, void *device);
 
 

@@ -17,6 +17,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -975,6 +976,74 @@ int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **devi
     if (e != hipSuccess) {
         (void)hipFree(d);
         return hip_fail(ctx, e, "hipMemcpy");
+    }
+    *device_out = d;
+    return MSSPE_OK;
+}
+
+int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                          size_t row_len, int pad, void **device_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!device_out || n_rows < 0 || (n_rows && (!rows || !row_bytes))) return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    *device_out = nullptr;
+    for (int r = 0; r < n_rows; ++r)
+        if (row_bytes[r] > row_len || (row_bytes[r] && !rows[r])) return fail(ctx, MSSPE_ERR_ARG, "row longer than row_len");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t total = row_len * (size_t)n_rows;
+    char *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, total ? total : 1));
+    if (!total) {
+        *device_out = d;
+        return MSSPE_OK;
+    }
+    // two pinned staging buffers: the host fills one (rows copied and padded by a few threads) while
+    // the DMA engine drains the other -- no rectangular copy of the whole matrix on the host
+    const size_t rows_per_chunk = std::max<size_t>(1, (size_t)(16u << 20) / std::max<size_t>(row_len, 1));
+    const size_t chunk_bytes = rows_per_chunk * row_len;
+    char *stage[2] = {nullptr, nullptr};
+    hipEvent_t drained[2] = {nullptr, nullptr};
+    hipStream_t copy = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipHostMalloc((void **)&stage[b], chunk_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&drained[b], hipEventDisableTiming);
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_threads = std::min<size_t>({(size_t)hw, 8, rows_per_chunk});
+    int turn = 0;
+    for (size_t r0 = 0; r0 < (size_t)n_rows && e == hipSuccess; r0 += rows_per_chunk, turn ^= 1) {
+        const size_t r1 = std::min<size_t>((size_t)n_rows, r0 + rows_per_chunk);
+        e = hipEventSynchronize(drained[turn]);   // the copy that last read this buffer (none: returns at once)
+        if (e != hipSuccess) break;
+        char *buf = stage[turn];
+        auto fill = [&](size_t a, size_t b) {
+            for (size_t r = a; r < b; ++r) {
+                char *dst = buf + (r - r0) * row_len;
+                if (row_bytes[r]) std::memcpy(dst, rows[r], row_bytes[r]);
+                std::memset(dst + row_bytes[r], pad, row_len - row_bytes[r]);
+            }
+        };
+        if (n_threads < 2) {
+            fill(r0, r1);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < n_threads; ++t)
+                pool.emplace_back(fill, r0 + (r1 - r0) * t / n_threads, r0 + (r1 - r0) * (t + 1) / n_threads);
+            for (auto &th : pool) th.join();
+        }
+        e = hipMemcpyAsync(d + r0 * row_len, buf, (r1 - r0) * row_len, hipMemcpyHostToDevice, copy);
+        if (e == hipSuccess) e = hipEventRecord(drained[turn], copy);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(copy);
+    for (int b = 0; b < 2; ++b) {
+        if (drained[b]) (void)hipEventDestroy(drained[b]);
+        if (stage[b]) (void)hipHostFree(stage[b]);
+    }
+    if (copy) (void)hipStreamDestroy(copy);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(ctx, e, "msspe_device_put_rows");
     }
     *device_out = d;
     return MSSPE_OK;

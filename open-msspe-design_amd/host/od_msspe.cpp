@@ -280,28 +280,14 @@ DeviceAlignment::DeviceAlignment(Engine &eng, const std::vector<SequenceRecord> 
     // winners are exactly those of the reference's per-record partitioning.
     for (const auto &r : records) len_ = std::max(len_, r.sequence.size());
     rows_ = (int)records.size();
-    const size_t total = len_ * records.size();
-    std::unique_ptr<char[]> flat(new char[total ? total : 1]);   // uninitialised: every byte is written below
-    auto fill = [&](size_t r0, size_t r1) {
-        for (size_t r = r0; r < r1; ++r) {
-            const std::string &seq = records[r].sequence;
-            char *row = flat.get() + r * len_;
-            std::memcpy(row, seq.data(), seq.size());
-            std::memset(row + seq.size(), '-', len_ - seq.size());
-        }
-    };
-    // large alignments: first touch and copy on several host threads
-    const size_t n_threads = std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), 16,
-                                               total / (8u << 20), records.size()});
-    if (n_threads < 2) {
-        fill(0, records.size());
-    } else {
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < n_threads; ++t)
-            pool.emplace_back(fill, records.size() * t / n_threads, records.size() * (t + 1) / n_threads);
-        for (auto &th : pool) th.join();
+    // rows go to the device through the library's pinned staging; no rectangular host copy
+    std::vector<const char *> rows(records.size());
+    std::vector<size_t> bytes(records.size());
+    for (size_t r = 0; r < records.size(); ++r) {
+        rows[r] = records[r].sequence.data();
+        bytes[r] = records[r].sequence.size();
     }
-    const int rc = msspe_device_put(eng.ctx(), flat.get(), total, &dev_);
+    const int rc = msspe_device_put_rows(eng.ctx(), rows.data(), bytes.data(), rows_, len_, '-', &dev_);
     if (rc) eng.fail(rc);
 }
 

@@ -16,7 +16,7 @@ EXPORTS = [
     "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
-    "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_host_split_tables", "msspe_segment_coverage", "msspe_segment_coverage_dev",
+    "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_host_split_tables", "msspe_device_put_rows", "msspe_segment_coverage", "msspe_segment_coverage_dev",
     "msspe_device_put", "msspe_device_free", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",

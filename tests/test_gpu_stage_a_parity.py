@@ -93,6 +93,38 @@ def test_mixed_tie_rates(eng, m, oracle, seed):
     run_both(eng, m, oracle, seqs, seg=200, stride=100, win=40, k=k, iters=int(rng.integers(1, 70)), mm=1)
 
 
+def test_rows_uploaded_through_pinned_staging(eng, m, oracle):
+    """msspe_device_put_rows: ragged rows (one string per record), padded with '-' on the way to the
+    device, enough of them for several staging chunks; stage A on that buffer equals stage A on the
+    rectangular host array and the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    base = m.synth.aligned_genomes(700, 30000)
+    rows = [bytes(r[: 30000 - int(rng.integers(0, 400))]) for r in base]     # 21 MB, ragged
+    rows[3] = b""
+    L = 30000
+    arr = np.full((len(rows), L), ord("-"), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        arr[i, : len(r)] = np.frombuffer(r, dtype=np.uint8)
+    ptrs = (C.c_char_p * len(rows))(*rows)
+    lens = (C.c_size_t * len(rows))(*[len(r) for r in rows])
+    dev = C.c_void_p()
+    eng.L.msspe_device_put_rows.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int,
+                                            C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+    eng.L.msspe_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    assert eng.L.msspe_device_put_rows(eng.ptr, ptrs, lens, len(rows), L, ord("-"), C.byref(dev)) == 0
+    try:
+        opt = m.KmerOpt(500, 250, 50, 13, 40, 3)
+        for d in (0, 1):
+            got = eng.kmer_candidates(None, opt, d, device_ptr=dev.value, n_seq=len(rows), seq_len=L)
+            want = eng.kmer_candidates(arr, opt, d)
+            assert got[0] == want[0] and got[1].tolist() == want[1].tolist() and len(got[0]) == 40
+    finally:
+        assert eng.L.msspe_device_free(eng.ptr, dev) == 0
+    seqs = [bytes(r).decode() for r in arr[:60]]
+    run_both(eng, m, oracle, seqs, iters=15, mm=2)
+
+
 def test_plain_launches_instead_of_graph_replays(eng, m, oracle, monkeypatch):
     """The greedy loop's fallback when hipGraph capture is not available."""
     monkeypatch.setenv("MSSPE_NO_GRAPH", "1")
