@@ -676,19 +676,21 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
                            stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, tied, M,
                            full);
     };
-    // both kinds of iteration captured once: [0] fast (three launches), [1] full (five)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    // captured once: [0] a batch of fast iterations (three launches each), [1] a batch of full
+    // iterations (five launches each), [2] one full iteration
+    constexpr int kBatch = 32;
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
     bool use_graph = std::getenv("MSSPE_NO_GRAPH") == nullptr;   // testing aid: plain launches
     if (use_graph) {
         // capture on a private stream so that the caller's stream may be of any kind
         hipStream_t cs = nullptr;
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) use_graph = false;
-        for (int full = 0; full < 2 && use_graph; ++full) {
+        for (int q = 0; q < 3 && use_graph; ++q) {
             if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                enqueue_iteration(cs, full);
-                if (hipStreamEndCapture(cs, &graph[full]) != hipSuccess || !graph[full] ||
-                    hipGraphInstantiate(&exec[full], graph[full], nullptr, nullptr, 0) != hipSuccess)
+                for (int b = 0; b < (q == 2 ? 1 : kBatch); ++b) enqueue_iteration(cs, q == 0 ? 0 : 1);
+                if (hipStreamEndCapture(cs, &graph[q]) != hipSuccess || !graph[q] ||
+                    hipGraphInstantiate(&exec[q], graph[q], nullptr, nullptr, 0) != hipSuccess)
                     use_graph = false;
             } else {
                 use_graph = false;
@@ -697,7 +699,6 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
         if (cs) (void)hipStreamDestroy(cs);
         (void)hipGetLastError();
     }
-    constexpr int kBatch = 32;
     Status h = h0;
     // Batches of fast iterations while ties are rare; a batch that met a tie idles from there on, the
     // host settles it with full iterations (a whole batch of them when ties come in numbers).
@@ -707,9 +708,10 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
         const int full = (full_mode || h.need_score) ? 1 : 0;
         const int n_now = (full && !full_mode) ? 1 : kBatch;   // one full iteration settles a lone tie
         const int scored_before = h.n_scored;
-        for (int b = 0; b < n_now; ++b) {
-            if (use_graph) KM_TRY(hipGraphLaunch(exec[full], stream));
-            else enqueue_iteration(stream, full);
+        if (use_graph) {
+            KM_TRY(hipGraphLaunch(exec[!full ? 0 : (n_now == 1 ? 2 : 1)], stream));
+        } else {
+            for (int b = 0; b < n_now; ++b) enqueue_iteration(stream, full);
         }
         launched += n_now;
         KM_TRY(hipGetLastError());
@@ -718,7 +720,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
         if (full_mode) full_mode = h.n_scored - scored_before >= 2;      // ties still frequent?
         else if (!full && h.need_score) full_mode = (long)(h.n_scored + 1) * kBatch > (long)h.n_win;   // a tie costs about a batch
     }
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         if (exec[q]) (void)hipGraphExecDestroy(exec[q]);
         if (graph[q]) (void)hipGraphDestroy(graph[q]);
     }
