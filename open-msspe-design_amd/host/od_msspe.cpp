@@ -635,6 +635,7 @@ struct PhaseTimer {
                      std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     }
+    ~PhaseTimer() { lap("teardown"); }   // declared first in run(): destroyed after everything else
 };
 }  // namespace
 
