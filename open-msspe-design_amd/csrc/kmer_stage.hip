@@ -42,9 +42,6 @@ struct Status {
     unsigned n_long;   // tied words with a long posting list (kept at the back of `tied`)
     unsigned ticket;   // last-block detection
     unsigned long long best;   // winner_key() maximum over the tied words
-    int need_score;    // fast iterations (no scoring kernels) met a tie: everything idles until a
-                       // full iteration has settled it
-    int n_scored;      // iterations that needed the scoring kernels (host heuristic)
 };
 
 // Segment ids are genome-major (seg = genome * P + partition: the order the reference walks
@@ -163,21 +160,17 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
 }
 
 // ---- greedy loop -------------------------------------------------------------------------------
-// One full iteration = k_max_count -> k_collect_tied -> k_tie_scores + k_tie_long -> k_cover, all with
+// One iteration = k_max_count -> k_collect_tied -> k_tie_scores + k_tie_long -> k_cover, all with
 // constant arguments.  Single-thread bookkeeping rides on the last block of k_max_count (decide)
 // and of k_cover (record the winner), found with a ticket counter.
-// Most iterations have ONE word at the maximum and need no scoring: the fast iteration is
-// k_max_count -> k_collect_tied -> k_cover (full = 0), in which k_cover takes the single candidate
-// itself; if it finds several it raises Status::need_score instead, which turns every fast kernel
-// into a no-op until the host has run one full iteration (full = 1).
 
 constexpr unsigned kLongList = 512;
 constexpr int kTieUnroll = 4;        // 1024-posting chunks whose loads k_tie_long keeps in flight   // posting lists above this get a whole block in k_tie_long
 
-__global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st, int full)
+__global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
 {
     __shared__ int part[4];
-    if (st->stop || (st->need_score && !full)) return;
+    if (st->stop) return;
     int m = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
         m = max(m, count[i]);
@@ -203,9 +196,9 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
 // Words tied at the maximum: short posting lists go to the front of `tied`, long ones to the back
 // (slot M-1-j).  Wave-aggregated so that a million-way tie costs thousands of atomics, not millions.
 __global__ void __launch_bounds__(256) k_collect_tied(const int32_t *count, int M, Status *st,
-                                                      const uint32_t *post_off, uint32_t *tied, int full)
+                                                      const uint32_t *post_off, uint32_t *tied)
 {
-    if (st->stop || (st->need_score && !full)) return;
+    if (st->stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool hit = i < M && count[i] == st->maxf;
@@ -366,27 +359,14 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                                                uint32_t *coverage, uint32_t *stamp, int P, int G,
                                                int per, const int32_t *kid_of_inst, int32_t *count,
                                                const uint64_t *ukeys, uint64_t *out_key,
-                                               uint32_t *out_freq, const uint32_t *tied, int M, int full)
+                                               uint32_t *out_freq)
 {
     __shared__ int32_t tile[64 * 33];
     __shared__ uint32_t rows_s[64];   // partition-major row of each posting, ~0u: nothing to do
     __shared__ int any_live;
-    if (st->stop || (st->need_score && !full)) return;
-    const unsigned n_cand = st->n_tied + st->n_long;
-    if (!full && n_cand != 1u) {   // several words at the maximum: a full iteration must score them
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
-                st->need_score = 1;
-                st->ticket = 0;
-            }
-        }
-        return;
-    }
+    if (st->stop) return;
     const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
-    // fast iteration: the single candidate (front of `tied`: short posting list, back: long one)
-    const uint32_t kid = full ? 0xffffffffu - (uint32_t)(st->best & 0xffffffffull)
-                              : (st->n_tied == 1u ? tied[0] : tied[(unsigned)M - 1u]);
+    const uint32_t kid = 0xffffffffu - (uint32_t)(st->best & 0xffffffffull);
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
@@ -459,8 +439,6 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
             st->winner = (int)kid;
             st->n_win += 1;
             if (mf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
-            if (full && n_cand != 1u) st->n_scored += 1;
-            st->need_score = 0;
             st->maxf = 0;
             st->best = 0;
             st->ticket = 0;
@@ -651,8 +629,8 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     KM_TRY(hipGetLastError());
 
     // 3. greedy loop: one iteration = five launches with constant arguments, captured once into a
-    //    hipGraph and replayed; the loop state (Status) lives on the device and the host only
-    //    looks at the stop flag every kBatch iterations.
+    //    hipGraph (kBatch iterations per graph) and replayed; the loop state (Status) lives on the
+    //    device and the host only looks at the stop flag between graphs.
     const int red_grid = std::min(128, (M + 255) / 256);
     const size_t tie_lds = 4 * sizeof(unsigned) * (size_t)((P + 31) / 32);
     Status h0;
@@ -662,72 +640,51 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     h0.min_freq = opt.max_mismatch_segments;
     KM_TRY(hipMemcpyAsync(st, &h0, sizeof h0, hipMemcpyHostToDevice, stream));
     KM_TRY(hipStreamSynchronize(stream));
-    auto enqueue_iteration = [&](hipStream_t s_, int full) {
-        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, s_, count, M, st, full);
+    auto enqueue_iteration = [&](hipStream_t s_) {
+        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, s_, count, M, st);
         hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
-                           post_off, tied, full);
-        if (full) {
-            hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
-                               ignored, coverage, (int)P, n_seq);
-            hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
-                               post, ignored, coverage, (int)P, n_seq);
-        }
+                           post_off, tied);
+        hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
+                           ignored, coverage, (int)P, n_seq);
+        hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
+                           post, ignored, coverage, (int)P, n_seq);
         hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, tied, M,
-                           full);
+                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq);
     };
-    // captured once: [0] a batch of fast iterations (three launches each), [1] a batch of full
-    // iterations (five launches each), [2] one full iteration
+    // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration:
+    // 29 -> 27 ms per direction at 10,000 genomes)
     constexpr int kBatch = 32;
-    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
-    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
     bool use_graph = std::getenv("MSSPE_NO_GRAPH") == nullptr;   // testing aid: plain launches
     if (use_graph) {
         // capture on a private stream so that the caller's stream may be of any kind
         hipStream_t cs = nullptr;
         if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) use_graph = false;
-        for (int q = 0; q < 3 && use_graph; ++q) {
-            if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                for (int b = 0; b < (q == 2 ? 1 : kBatch); ++b) enqueue_iteration(cs, q == 0 ? 0 : 1);
-                if (hipStreamEndCapture(cs, &graph[q]) != hipSuccess || !graph[q] ||
-                    hipGraphInstantiate(&exec[q], graph[q], nullptr, nullptr, 0) != hipSuccess)
-                    use_graph = false;
-            } else {
+        if (use_graph && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int b = 0; b < kBatch; ++b) enqueue_iteration(cs);
+            if (hipStreamEndCapture(cs, &graph) != hipSuccess || !graph ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 use_graph = false;
-            }
+        } else {
+            use_graph = false;
         }
         if (cs) (void)hipStreamDestroy(cs);
         (void)hipGetLastError();
     }
     Status h = h0;
-    // Batches of fast iterations while ties are rare; a batch that met a tie idles from there on, the
-    // host settles it with full iterations (a whole batch of them when ties come in numbers).
-    bool full_mode = false;
-    const long launch_budget = 40L * ((long)h0.max_iter + 2) + 8L * kBatch;   // safety net: every batch pair makes progress
-    for (long launched = 0; launched < launch_budget && !h.stop;) {
-        const int full = (full_mode || h.need_score) ? 1 : 0;
-        const int n_now = (full && !full_mode) ? 1 : kBatch;   // one full iteration settles a lone tie
-        const int scored_before = h.n_scored;
+    for (int done = 0; done < h0.max_iter + 1 && !h.stop; done += kBatch) {
         if (use_graph) {
-            KM_TRY(hipGraphLaunch(exec[!full ? 0 : (n_now == 1 ? 2 : 1)], stream));
+            KM_TRY(hipGraphLaunch(exec, stream));
         } else {
-            for (int b = 0; b < n_now; ++b) enqueue_iteration(stream, full);
+            for (int b = 0; b < kBatch; ++b) enqueue_iteration(stream);
         }
-        launched += n_now;
         KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
-        if (full_mode) full_mode = h.n_scored - scored_before >= 2;      // ties still frequent?
-        else if (!full && h.need_score) full_mode = (long)(h.n_scored + 1) * kBatch > (long)h.n_win;   // a tie costs about a batch
     }
-    for (int q = 0; q < 3; ++q) {
-        if (exec[q]) (void)hipGraphExecDestroy(exec[q]);
-        if (graph[q]) (void)hipGraphDestroy(graph[q]);
-    }
-    if (!h.stop) {
-        err = "stage A: the greedy loop did not finish within its launch budget";
-        return MSSPE_ERR_DEVICE;
-    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
     const int n_win = h.n_win;
     if (h.maxf > 1 && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
         // the caller's buffers ended the loop, not the reference's rules

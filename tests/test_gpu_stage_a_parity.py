@@ -74,10 +74,9 @@ def test_small_parameters_and_ties(eng, m, oracle):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_mixed_tie_rates(eng, m, oracle, seed):
-    """Alignments whose tie rate ranges from rare to constant: the greedy loop switches between its
-    fast iterations (single word at the maximum), single full iterations (a lone tie) and batches
-    of full iterations, at batch boundaries and in mid-batch, and must emit the reference's winners
-    whatever the schedule; with and without a cap on the iterations."""
+    """Alignments whose rate of frequency ties ranges from rare to constant (single candidates skip
+    the scoring, ties go through partition_tie_score), with and without a cap on the iterations
+    (the loop ends in mid-batch of its graph replays)."""
     rng = np.random.default_rng(100 + seed)
     rows, length = int(rng.integers(12, 90)), int(rng.integers(1500, 5000))
     rate = [0.002, 0.01, 0.03, 0.08, 0.15, 0.3, 0.01, 0.05][seed]
