@@ -172,8 +172,16 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
     __shared__ int part[4];
     if (st->stop) return;
     int m = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
-        m = max(m, count[i]);
+    {
+        // 16-byte loads (the count array is 256-byte aligned), the last M % 4 words one by one
+        const int4 *c4 = reinterpret_cast<const int4 *>(count);
+        const int M4 = M >> 2, tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+        for (int i = tid; i < M4; i += stride) {
+            const int4 v = c4[i];
+            m = max(m, max(max(v.x, v.y), max(v.z, v.w)));
+        }
+        for (int i = (M4 << 2) + tid; i < M; i += stride) m = max(m, count[i]);
+    }
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
