@@ -588,6 +588,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             a.overflow_list = ctx->ovf_list;
             a.overflow_count = ctx->ovf_count;
             a.overflow_cap = (uint32_t)kListCap;
+            a.work_counter = ctx->ovf_count + 7;   // the last of the eight stage counters
             if (ctx->prof_on) {
                 if (ctx->prof_used == ctx->prof_events.size()) {
                     hipEvent_t e0, e1;

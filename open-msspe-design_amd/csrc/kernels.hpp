@@ -76,6 +76,7 @@ struct PairKernelArgs {
     uint2 *overflow_list;
     uint32_t *overflow_count;
     uint32_t overflow_cap;
+    uint32_t *work_counter;        // device word for the integer first stage's work queue (launch_pairs_int)
 };
 hipError_t launch_pairs_fast(const PairKernelArgs &a, hipStream_t stream);
 // The main table over an explicit pair list (what the integer stage handed on); pairs that do not

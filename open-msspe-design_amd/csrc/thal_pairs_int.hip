@@ -545,6 +545,7 @@ struct IntArgs {
                                    // [8] samples kept, [9 ... 1032] samples; the list mode counts at
                                    // [1033 ...] (same layout, no samples)
     int stat_off;                  // 0 (matrix mode) or 1033 (list mode)
+    unsigned *work_counter;        // matrix mode: next work item (one row x 64 sorted columns), zero at launch
 };
 
 // A list entry whose pair needs the f64 kernels (an exact tie was met) carries this bit in .x;
@@ -657,16 +658,20 @@ __global__ void __launch_bounds__(THREADS) k_pairs_int(IntArgs a)
     typedef SharedI<NS, THREADS, TROWS> SH;
     __shared__ SH sh;
     load_tables_int(sh, a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kRowsPerBlock = THREADS / 64;
+    const int lane = threadIdx.x & 63;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
-    const int nrowg = (a.f.row1 - a.f.row0 + kRowsPerBlock - 1) / kRowsPerBlock;
-    const long tiles = (long)ncolg * nrowg;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int rg = (int)(tile / ncolg), cg = (int)(tile % ncolg);
-        const int row = a.f.row0 + rg * kRowsPerBlock + wave;
+    // Work items (one row x 64 consecutive sorted columns) are handed out to the WAVES from a
+    // counter: a block's waves need not march together, and the composition-sorted column groups
+    // (whose cost differs by up to 20 % between the ends and the middle of the order) no longer
+    // fall to fixed blocks.
+    const unsigned n_items = (unsigned)ncolg * (unsigned)(a.f.row1 - a.f.row0);
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.work_counter, 1u);
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= n_items) break;   // wave-uniform
+        const int row = a.f.row0 + (int)(item / (unsigned)ncolg), cg = (int)(item % (unsigned)ncolg);
         const int cq = a.f.col0 + cg * 64 + lane;
-        if (row >= a.f.row1) continue;   // wave-uniform
         const bool inside = cq < a.f.col1;
         const uint64_t pa = a.f.pool[row];
         const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
@@ -786,6 +791,8 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
     x.it = it;
     x.reasons = reasons;
     x.stat_off = 0;
+    x.work_counter = a.work_counter;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     // one persistent block per CU (about 150 KB of LDS each)
     if (a.k <= 13) {
         constexpr int kRowsPerBlock = kThreadsSmall / 64;
@@ -831,6 +838,7 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
     x.it = it;
     x.reasons = reasons;
     x.stat_off = 1033;
+    x.work_counter = nullptr;
     hipLaunchKernelGGL(k_pairs_int_list, dim3(256), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }
