@@ -451,6 +451,7 @@ struct SplitArgs {
     uint32_t *ovf_count;
     uint32_t ovf_cap;
     unsigned long long *reasons;   // optional statistics, layout of thal_pairs_int.hip's matrix mode
+    unsigned *work_counter;        // next work item, zero at launch
 };
 
 __device__ __forceinline__ void load_tables_s(SharedS &sh, const SplitArgs &a)
@@ -474,16 +475,19 @@ __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
 {
     __shared__ SharedS sh;
     load_tables_s(sh, a);
-    constexpr int kPairsPerWave = 64 / Q, kRowsPerBlock = kThreadsS / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kPairsPerWave = 64 / Q;
+    const int lane = threadIdx.x & 63;
     const int ncolg = (a.col1 - a.col0 + kPairsPerWave - 1) / kPairsPerWave;
-    const int nrowg = (a.row1 - a.row0 + kRowsPerBlock - 1) / kRowsPerBlock;
-    const long tiles = (long)ncolg * nrowg;
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int rg = (int)(tile / ncolg), cg = (int)(tile % ncolg);
-        const int row = a.row0 + rg * kRowsPerBlock + wave;
+    // work items (one row x 64 / Q consecutive sorted columns) are handed to the waves from a counter
+    // (fixed strides would tie every block to a few composition classes of very different cost)
+    const unsigned n_items = (unsigned)ncolg * (unsigned)(a.row1 - a.row0);
+    for (;;) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(a.work_counter, 1u);
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= n_items) break;   // wave-uniform
+        const int row = a.row0 + (int)(item / (unsigned)ncolg), cg = (int)(item % (unsigned)ncolg);
         const int cq = a.col0 + cg * kPairsPerWave + lane / Q;
-        if (row >= a.row1) continue;   // wave-uniform
         const bool inside = cq < a.col1;
         const bool head = (lane & (Q - 1)) == 0;   // the lane that reports for its group
         const uint64_t pa = a.pool[row];
@@ -569,6 +573,8 @@ hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, un
     x.ovf_count = a.overflow_count;
     x.ovf_cap = a.overflow_cap;
     x.reasons = reasons;
+    x.work_counter = a.work_counter;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     const int Q = pairs_split_lanes(a.k);
     const long tiles = (long)((a.col1 - a.col0 + 64 / Q - 1) / (64 / Q)) * (long)((a.row1 - a.row0 + 7) / 8);
     if (tiles <= 0) return hipSuccess;
