@@ -494,6 +494,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         a.col0 = 0;
         a.col1 = ncols;
         a.sinks = sinks;
+        a.work_counter = ctx->ovf_count + 7;
         // list A (ovf_list, counter 0) = what the first stage did not answer
         const uint2 *in_list = ctx->ovf_list;
         uint2 *out_list = ctx->ovf_list2;

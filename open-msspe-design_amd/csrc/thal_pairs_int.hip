@@ -697,7 +697,13 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
     const long n_work = (long)min(*a.f.in_count, a.f.ovf_cap);
     const long batch = (long)kListBatchI * kThreadsI;
     const long n_batches = (n_work + batch - 1) / batch;
-    for (long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
+    __shared__ unsigned next_batch;
+    for (;;) {
+        // batches are handed out from a counter (a block's batches differ in cost with the table sizes)
+        if (threadIdx.x == 0) next_batch = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        const long bt = (long)next_batch;
+        if (bt >= n_batches) break;   // block-uniform
         uint2 mine[kListBatchI];
         int key[kListBatchI];
         for (int e = threadIdx.x; e < 256; e += kThreadsI) hist[e] = 0u;
@@ -838,7 +844,8 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
     x.it = it;
     x.reasons = reasons;
     x.stat_off = 1033;
-    x.work_counter = nullptr;
+    x.work_counter = a.work_counter;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pairs_int_list, dim3(256), dim3(kThreadsI), 0, stream, x);
     return hipGetLastError();
 }
