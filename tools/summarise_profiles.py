@@ -61,7 +61,8 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write("## derived\n")
     f.write(f"VALU instructions per check (per lane)      {c1['SQ_INSTS_VALU'] / waves:.0f}\n")
     f.write(f"SALU / LDS / branch per wave-batch          {c1['SQ_INSTS_SALU'] / waves:.0f} / {c1['SQ_INSTS_LDS'] / waves:.0f} / {c1['SQ_INSTS_BRANCH'] / waves:.0f}\n")
-    f.write(f"VALU busy share of all SIMD issue slots     {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}\n")
+    f.write(f"VALU busy share of all SIMD issue slots     {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}"
+            f"   (one wave instruction per SIMD per 4 cycles = 1.0; the clock is GRBM_GUI_ACTIVE / 8 / time, good to a few %)\n")
     f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
@@ -80,7 +81,8 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
     "valu_instructions_per_check": c1["SQ_INSTS_VALU"] / waves,
     "salu_instructions_per_wave_batch": c1["SQ_INSTS_SALU"] / waves,
     "lds_instructions_per_wave_batch": c1["SQ_INSTS_LDS"] / waves,
-    "valu_busy_fraction": c2["SQ_ACTIVE_INST_VALU"] / simd_quads,
+    "valu_busy_fraction": min(1.0, c2["SQ_ACTIVE_INST_VALU"] / simd_quads),
+    "valu_busy_counter_ratio": c2["SQ_ACTIVE_INST_VALU"] / simd_quads,
     "int32_valu_peak_tops": 256 * 4 * 16 * clock_ghz / 1e3,
     "achieved_int32_tops": c1["SQ_INSTS_VALU"] * 64 / (ms1 * 1e-3) / 1e12,
     "clock_ghz": clock_ghz}, indent=1))
