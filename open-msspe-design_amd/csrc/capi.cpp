@@ -839,7 +839,7 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         if (wave_ok) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
             HIP_TRY(ctx, launch_self_wave(ce->d_st, ce->c[0], d_pool, k, 0, n, pass == 1, dst, ctx->ovf_list,
-                                          ctx->ovf_count, (uint32_t)ctx->list_cap, ctx->stream));
+                                          ctx->ovf_count, (uint32_t)ctx->list_cap, ctx->ovf_count + 7, ctx->stream));
             g.list = ctx->ovf_list;
             g.list_count = ctx->ovf_count;
         }

@@ -111,7 +111,7 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
 // max(0, t); what it does not take is appended to list as (row, row).
 hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
                             int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
-                            uint32_t list_cap, hipStream_t stream);
+                            uint32_t list_cap, uint32_t *work_counter, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
 int pool_sort_bins();

@@ -57,6 +57,7 @@ struct WaveArgs {
     // (row0 + w, row0 + w), result self_t[row] = max(0, t); end1: thal END1 instead of ANY
     double *self_t;
     int end1;
+    unsigned *work_counter;          // next work item, zero at launch
 };
 
 // all lanes of the wave end up with the same value
@@ -295,8 +296,12 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
     const long ncols = a.col1 - a.col0;
     const long n_work = a.self_t ? (long)(a.row1 - a.row0)
                                  : (a.in_list ? (long)min(*a.in_count, a.in_cap) : (long)(a.row1 - a.row0) * ncols);
-    const long stride = (long)gridDim.x * kWavesPerBlock;
-    for (long w = (long)blockIdx.x * kWavesPerBlock + wave; w < n_work; w += stride) {
+    for (;;) {
+        // pairs are handed to the waves from a counter: their cost ranges over an order of magnitude
+        unsigned next = 0;
+        if (lane == 0) next = atomicAdd(a.work_counter, 1u);
+        const long w = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
+        if (w >= n_work) break;   // wave-uniform
         int row, col;
         if (a.self_t) {
             row = col = a.row0 + (int)w;
@@ -316,26 +321,28 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
         r.dG = INFINITY;
         r.t = 0.0;
         const bool fits = !sym && run_pair_wave(sh, wave, a.c, pa, pb, a.k, a.end1 != 0, r);
-        if (lane != 0) continue;
-        if (!fits) {
-            const uint32_t at = atomicAdd(a.ovf_count, 1u);
-            if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
-            continue;
+        // lane 0 reports; no lane may run ahead into the next fetch (readfirstlane reads the first
+        // ACTIVE lane), so there is no early `continue` here: the wave reconverges at the loop's end
+        if (lane == 0) {
+            if (!fits) {
+                const uint32_t at = atomicAdd(a.ovf_count, 1u);
+                if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
+            } else if (a.self_t) {
+                a.self_t[row] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
+            } else {
+                const size_t orow = (size_t)(row - a.sinks.row0);
+                const size_t ocol = (size_t)(col - a.sinks.col0);
+                if (r.conflict) {
+                    if (a.sinks.bitmap)
+                        atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
+                                 1ull << (ocol & 63));
+                    if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[row], 1u);
+                }
+                if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
+                if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
+            }
         }
-        if (a.self_t) {
-            a.self_t[row] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
-            continue;
-        }
-        const size_t orow = (size_t)(row - a.sinks.row0);
-        const size_t ocol = (size_t)(col - a.sinks.col0);
-        if (r.conflict) {
-            if (a.sinks.bitmap)
-                atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
-                         1ull << (ocol & 63));
-            if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[row], 1u);
-        }
-        if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
-        if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -363,7 +370,9 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
     x.ovf_cap = a.overflow_cap;
     x.self_t = nullptr;
     x.end1 = 0;
+    x.work_counter = a.work_counter;
     if (!in_list && ((long)(a.row1 - a.row0) * (long)(a.col1 - a.col0) <= 0)) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pairs_wave, dim3(256 * 2), dim3(kThreadsW), 0, stream, x);
     return hipGetLastError();
 }
@@ -373,7 +382,7 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
 // list as (row, row) for launch_dimer_generic.
 hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
                             int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
-                            uint32_t list_cap, hipStream_t stream)
+                            uint32_t list_cap, uint32_t *work_counter, hipStream_t stream)
 {
     WaveArgs x;
     std::memset(&x, 0, sizeof x);
@@ -390,7 +399,9 @@ hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const ui
     x.ovf_cap = list_cap;
     x.self_t = self_t;
     x.end1 = end1 ? 1 : 0;
+    x.work_counter = work_counter;
     if (row1 <= row0) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     const int blocks = (row1 - row0 + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(k_pairs_wave, dim3(blocks < 512 ? blocks : 512), dim3(kThreadsW), 0, stream, x);
     return hipGetLastError();
