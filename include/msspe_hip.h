@@ -68,6 +68,18 @@ const char *msspe_last_error(const msspe_ctx *ctx);
 const char *msspe_version(void);
 /* Use the caller's hipStream_t (e.g. PyTorch's current stream) for every later call; NULL is
  * HIP's default (null) stream.  msspe_reset_stream() returns to the context's own stream. */
+/* Engine options: which kernels later calls may use.  Nothing in the library reads the process
+ * environment; the defaults are the product path and the other values exist so that the parity tests
+ * can run every stage against every other (the reference has no equivalent: its only knobs are the
+ * --ntthal / --primer3 paths, od-msspe/src/config.rs:142-147).  Unknown key / bad value: MSSPE_ERR_ARG.
+ *   "pair_kernel"    "auto" | "f64" (f64 register-table kernel first) | "int" (general integer kernel first)
+ *   "force_generic"  "0" | "1"    dense one-lane-per-pair kernels only
+ *   "split_min_k"    "2".."99"    shortest oligo that goes to the split-table kernel (15)
+ *   "wave_kernel"    "0" | "1"    one-wave-per-pair f64 kernel in the chain (1)
+ *   "list_cap_log2"  "0" | "20".."30"   fixed hand-over list size (0: sized by the call)
+ *   "split_lanes"    "0" | "2" | "4" | "8"
+ *   "stage_a_graph"  "0" | "1"    hipGraph replay of stage A's greedy loop (1) */
+int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value);
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
 int msspe_reset_stream(msspe_ctx *ctx);
 int msspe_synchronize(msspe_ctx *ctx);

@@ -50,8 +50,21 @@ constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' wo
 
 }  // namespace
 
+// Engine options (msspe_set_option): which kernels a call may use.  Defaults are the product path;
+// the rest exists for the parity tests (every stage against every other) and for experiments.
+struct EngineOptions {
+    int pair_kernel = 0;      // 0 auto | 1 f64 register-table kernel first | 2 general integer kernel first
+    bool force_generic = false;
+    int split_min_k = 15;     // measured on 8,192 primers: k = 14 register tables 516 vs 250 M checks/s, k = 15 198 vs 202, k = 16 41 vs 165
+    bool wave_kernel = true;
+    int list_cap_log2 = 0;    // 0: sized by the call; 20..30: fixed (forces flushes mid-screen)
+    int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
+};
+
 struct msspe_ctx {
     int device = 0;
+    int n_cu = 256;
+    EngineOptions opt;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     NNTables host_tb;
@@ -171,37 +184,45 @@ int ensure_workspace(msspe_ctx *ctx, size_t cells_per_lane)
 }
 
 // The lists are sized by the call (every pair could be handed on between two flushes): small
-// screens keep small lists, the 65,536-primer screen flushes every 32 launches.
+// screens keep small lists, the 65,536-primer screen flushes every 8 launches.
 int ensure_overflow(msspe_ctx *ctx, long total_pairs)
 {
+    // the small counter buffers first and unconditionally: a failed list allocation must not leave a
+    // context whose counters are missing
+    if (!ctx->ovf_count) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 8));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, sizeof(uint32_t) * 8, ctx->stream));
+    }
+    if (!ctx->d_ovf_total) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, sizeof(uint64_t), ctx->stream));
+    }
+    if (!ctx->d_reasons) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024 + 8) * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_reasons, 0, (9 + 1024 + 8) * sizeof(unsigned long long), ctx->stream));
+    }
     long want = kListCapMin;
     while (want < total_pairs && want < kListCapMax) want <<= 1;
-    if (const char *e = std::getenv("MSSPE_LIST_CAP_LOG2")) {   // testing aid: force flushes mid-screen
-        const long lg = std::strtol(e, nullptr, 10);
-        if (lg >= 27 && lg <= 30) want = 1L << lg;
-    }
-    if (ctx->ovf_list && (ctx->list_cap == want || (ctx->list_cap > want && !std::getenv("MSSPE_LIST_CAP_LOG2"))))
-        return MSSPE_OK;
-    if (ctx->ovf_list) {
+    const bool fixed = ctx->opt.list_cap_log2 >= 20 && ctx->opt.list_cap_log2 <= 30;
+    if (fixed) want = 1L << ctx->opt.list_cap_log2;
+    if (ctx->ovf_list && ctx->ovf_list2 && (ctx->list_cap == want || (ctx->list_cap > want && !fixed))) return MSSPE_OK;
+    if (ctx->ovf_list || ctx->ovf_list2) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->ovf_list);
-        (void)hipFree(ctx->ovf_list2);
+        if (ctx->ovf_list) (void)hipFree(ctx->ovf_list);
+        if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
         ctx->ovf_list = ctx->ovf_list2 = nullptr;
         ctx->list_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want));
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want));
-        ctx->list_cap = want;
-        return MSSPE_OK;
     }
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want));
+    hipError_t e1 = hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want);
+    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want) : e1;
+    if (e1 != hipSuccess || e2 != hipSuccess) {   // all or nothing: a later call starts from a clean state
+        if (ctx->ovf_list) (void)hipFree(ctx->ovf_list);
+        if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
+        ctx->ovf_list = ctx->ovf_list2 = nullptr;
+        ctx->list_cap = 0;
+        return hip_fail(ctx, e1 != hipSuccess ? e1 : e2, "hipMalloc(hand-over lists)");
+    }
     ctx->list_cap = want;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->ovf_count, sizeof(uint32_t) * 8));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMemset(ctx->ovf_count, 0, sizeof(uint32_t) * 8));
-    HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024 + 8) * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, (9 + 1024 + 8) * sizeof(unsigned long long)));
     return MSSPE_OK;
 }
 
@@ -224,28 +245,6 @@ int ensure_sort(msspe_ctx *ctx, size_t ncols)
 __global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *total += *count;
-}
-
-bool use_generic_only()
-{
-    const char *e = std::getenv("MSSPE_FORCE_GENERIC");
-    return e && *e && *e != '0';
-}
-
-// Shortest oligo that goes to the split-table kernel (thal_pairs_split.hip) instead of the
-// register-table chain; MSSPE_SPLIT_MIN_K overrides it (experiments).
-int split_min_k()
-{
-    if (const char *e = std::getenv("MSSPE_SPLIT_MIN_K")) return std::atoi(e);
-    return 15;   // measured on 8,192 primers: k = 14 register tables 516 vs 250 M checks/s, k = 15 198 vs 202, k = 16 41 vs 165
-}
-
-// MSSPE_PAIR_KERNEL=f64 keeps the f64 register-table kernel as the first stage (testing aid);
-// the default first stage is the exact-integer kernel, with the f64 kernels behind it.
-bool use_f64_pairs()
-{
-    const char *e = std::getenv("MSSPE_PAIR_KERNEL");
-    return e && std::strcmp(e, "f64") == 0;
 }
 
 }  // namespace
@@ -299,10 +298,49 @@ int msspe_create(int device, const char *params_path, msspe_ctx **out)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, MSSPE_ERR_DEVICE,
                     std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tb, sizeof(NNTables)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_tb, &ctx->host_tb, sizeof(NNTables), hipMemcpyHostToDevice));
+    return MSSPE_OK;
+}
+
+int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!key || !value) return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: null key or value");
+    const std::string k(key), v(value);
+    char *end = nullptr;
+    const long num = std::strtol(value, &end, 10);
+    const bool is_num = end && end != value && *end == '\0';
+    auto bad = [&]() { return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: bad value '" + v + "' for '" + k + "'"); };
+    if (k == "pair_kernel") {
+        if (v == "auto") ctx->opt.pair_kernel = 0;
+        else if (v == "f64") ctx->opt.pair_kernel = 1;
+        else if (v == "int") ctx->opt.pair_kernel = 2;
+        else return bad();
+    } else if (k == "force_generic") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->opt.force_generic = num != 0;
+    } else if (k == "split_min_k") {
+        if (!is_num || num < 2 || num > 99) return bad();
+        ctx->opt.split_min_k = (int)num;
+    } else if (k == "wave_kernel") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->opt.wave_kernel = num != 0;
+    } else if (k == "list_cap_log2") {
+        if (!is_num || !(num == 0 || (num >= 20 && num <= 30))) return bad();
+        ctx->opt.list_cap_log2 = (int)num;
+    } else if (k == "split_lanes") {
+        if (!is_num || !(num == 0 || num == 2 || num == 4 || num == 8)) return bad();
+        ctx->opt.split_lanes = (int)num;
+    } else if (k == "stage_a_graph") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->kmer.set_use_graph(num != 0);
+    } else {
+        return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: unknown option '" + k + "'");
+    }
     return MSSPE_OK;
 }
 
@@ -415,14 +453,14 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     const int words = (ncols + 63) / 64;
     // long oligos: exact-integer kernel with a pair's table split over lanes (honours max_loop)
     // (also short oligos under a loop-size limit the register-table kernels do not implement)
-    const bool split = !use_generic_only() && !use_f64_pairs() && k <= ce->split_max_k &&
-                       (k >= split_min_k() || chem->max_loop < 2 * k - 4);
+    const bool split = !ctx->opt.force_generic && !(ctx->opt.pair_kernel == 1) && k <= ce->split_max_k &&
+                       (k >= ctx->opt.split_min_k || chem->max_loop < 2 * k - 4);
     // f64, one wave per pair: behind the split kernel, and as the first stage where neither the split
     // kernel nor the register-table chain applies (29 .. 32 bases, parameter files off the grid)
-    const bool wave_ok = !use_generic_only() && k <= ce->wave_max_k && std::getenv("MSSPE_NO_WAVE_KERNEL") == nullptr;
+    const bool wave_ok = !ctx->opt.force_generic && k <= ce->wave_max_k && ctx->opt.wave_kernel;
     const bool wave_matrix = wave_ok && !split && (k > pairs_fast_max_k() || chem->max_loop < 2 * k - 4);
     const bool fast = split || wave_matrix ||
-                      (!use_generic_only() && k <= pairs_fast_max_k() && ce->fast_ok &&
+                      (!ctx->opt.force_generic && k <= pairs_fast_max_k() && ce->fast_ok &&
                        chem->max_loop >= 2 * k - 4);   // the tuned kernel has no loop-size cut-off
     // the conflict bitmap is produced with atomic ORs: clear the caller's block first
     if (d_bitmap)
@@ -470,7 +508,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         }
         return MSSPE_OK;
     }
-    const bool int_stage = !split && ce->int_ok && !use_f64_pairs();
+    const bool int_stage = !split && ce->int_ok && !(ctx->opt.pair_kernel == 1);
     if (!wave_matrix) {
         if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
         HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
@@ -532,7 +570,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             a.overflow_count = ctx->ovf_count + out_c;
             a.overflow_cap = (uint32_t)kListCap;
             HIP_TRY(ctx, launch_pairs_int_list(a, ce->d_it, in_list, ctx->ovf_count + in_c, ctx->d_reasons,
-                                               ctx->stream));
+                                               ctx->n_cu, ctx->stream));
             advance();
             a.overflow_list = out_list;
             a.overflow_count = ctx->ovf_count + out_c;
@@ -603,8 +641,10 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                 a.col0 = col0 + (int)q0;   // pool columns, no composition sort
                 a.col1 = col0 + (int)q_end;
                 HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
-            } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->stream));
-            else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->stream));
+            } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->opt.split_lanes, ctx->stream));
+            else if (int_stage && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
+                HIP_TRY(ctx, launch_pairs_row(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
+            else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));
             if (ctx->prof_on)
                 HIP_TRY(ctx, hipEventRecord(ctx->prof_events[ctx->prof_used++].second, ctx->stream));
@@ -648,7 +688,7 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(count_out, ctx->d_ovf_total, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemset(ctx->d_ovf_total, 0, sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, sizeof(uint64_t), ctx->stream));
     return MSSPE_OK;
 }
 
@@ -661,8 +701,8 @@ int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[16])
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_reasons, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(out + 8, ctx->d_reasons + 1033, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons, 0, 9 * sizeof(uint64_t)));
-    HIP_TRY(ctx, hipMemset(ctx->d_reasons + 1033, 0, 8 * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_reasons, 0, 9 * sizeof(uint64_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_reasons + 1033, 0, 8 * sizeof(uint64_t), ctx->stream));
     return MSSPE_OK;
 }
 
@@ -716,11 +756,11 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
     TRY_OR_CLEAN(hipMemcpy(d_pool, packed.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
     if (row_conflicts) {
         TRY_OR_CLEAN(hipMalloc((void **)&d_rc, sizeof(uint32_t) * (size_t)n));
-        TRY_OR_CLEAN(hipMemset(d_rc, 0, sizeof(uint32_t) * (size_t)n));
+        TRY_OR_CLEAN(hipMemsetAsync(d_rc, 0, sizeof(uint32_t) * (size_t)n, ctx->stream));   // on the stream the kernels run on (it is non-blocking: the null stream does not order against it)
     }
     if (bitmap) {
         TRY_OR_CLEAN(hipMalloc((void **)&d_bitmap, sizeof(uint64_t) * (size_t)n * words));
-        TRY_OR_CLEAN(hipMemset(d_bitmap, 0, sizeof(uint64_t) * (size_t)n * words));
+        TRY_OR_CLEAN(hipMemsetAsync(d_bitmap, 0, sizeof(uint64_t) * (size_t)n * words, ctx->stream));
     }
     if (dg) TRY_OR_CLEAN(hipMalloc((void **)&d_dg, sizeof(double) * nn));
     if (tm) TRY_OR_CLEAN(hipMalloc((void **)&d_tm, sizeof(double) * nn));
@@ -817,7 +857,7 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                                      d_tm, d_gc, ctx->stream));
     // SELF_ANY / SELF_END: one wave per oligo (thal_pairs_wave.hip); the dense kernel, one lane per
     // oligo, only takes what that kernel leaves (self-complementary oligos, oversized tables)
-    const bool wave_ok = !use_generic_only() && k <= ce->wave_max_k && std::getenv("MSSPE_NO_WAVE_KERNEL") == nullptr;
+    const bool wave_ok = !ctx->opt.force_generic && k <= ce->wave_max_k && ctx->opt.wave_kernel;
     if (wave_ok && (rc = ensure_overflow(ctx, n))) return rc;
     for (int pass = 0; pass < 2; ++pass) {
         double *dst = pass == 0 ? d_self_any : d_self_end;

@@ -1,0 +1,129 @@
+// int_core.hpp -- pieces shared by the exact-integer all-pairs kernels: thal_pairs_int.hip (list mode and
+// the 14..16-base matrix shape) and thal_pairs_row.hip (matrix mode with a table specialised to the
+// block's row primer).  Reference path: /root/reference/od-msspe/src/delta_g.rs:61-153 (one thal ANY per
+// ordered pair); Primer3 2.6.1 thal() restated from SURVEY.md Appendix C.3.
+#pragma once
+
+#include "pair_core.hpp"
+
+namespace msspe {
+
+namespace {
+
+constexpr int kC = 4;              // slots per chunk (= predecessor evaluations in flight)
+// Two shapes of the matrix-mode kernel.  Oligos up to 13 bases need 189 rows of the loop table,
+// which leaves LDS for a 768-thread block: with 48 slots the kernel fits 168 VGPRs, i.e. THREE
+// waves per SIMD (the scan is VALU-bound, the rest of a cell latency-bound: the third wave fills
+// the gaps); pairs with more cells (11 %) go to the list mode.  Longer oligos: 512 threads, 56 slots.
+constexpr int kSlotsSmall = 52, kThreadsSmall = 768, kRowsSmall = 11 * 17 + 2;   // k <= 13
+constexpr int kSlotsMatrix = 56;   // k <= 16 (the largest tables drag their waves)
+constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
+constexpr int kThreadsI = 512;
+constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
+constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
+constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
+
+// slot s: G[s] = exact 2000 * dG of the cell value; W[s] = h << 16 | po << 10 | im1 << 4 | jm1
+// (bits 8, 9 zero, so that bits 8..15 read as po * 4, a byte offset).  The predecessor of the
+// cell (im1 << 4 | jm1, 0xff: none) is only read by the traceback and lives in LDS.
+// The table is kept as register tuples, plain local values (32 + 16 + 8 elements per plane for 56
+// slots, 32 + 32 for 64): reads use compile-time element numbers, and the one write per cell goes
+// through the wave-uniform slot number (s_set_gpr_idx + v_mov), so publishing a cell needs no
+// branch tree and no register copies.  (They must stay plain locals passed by value: behind a
+// struct or a reference the compiler leaves them in scratch memory.)
+typedef int v32i __attribute__((ext_vector_type(32)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+template <int NS>
+struct TabTypes;
+template <>
+struct TabTypes<56> {
+    typedef v16i B;
+    typedef v8i C;
+};
+template <>
+struct TabTypes<48> {
+    typedef v16i B;
+    typedef v8i C;   // unused
+};
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <>
+struct TabTypes<52> {
+    typedef v16i B;
+    typedef v4i C;
+};
+template <>
+struct TabTypes<64> {
+    typedef v32i B;
+    typedef v8i C;   // unused
+};
+#define MSSPE_TAB_PARAMS                                                                                   \
+    const v32i Ga, const v32i Wa, const typename TabTypes<NS>::B Gb, const typename TabTypes<NS>::B Wb, \
+        const typename TabTypes<NS>::C Gc, const typename TabTypes<NS>::C Wc
+#define MSSPE_TAB_ARGS Ga, Wa, Gb, Wb, Gc, Wc
+
+template <int NS>
+__device__ __forceinline__ int slot_of(const v32i a, const typename TabTypes<NS>::B b,
+                                       const typename TabTypes<NS>::C c, int x)
+{
+    if constexpr (NS == 56) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 7]);
+    else if constexpr (NS == 48) return x < 32 ? a[x & 31] : b[(x - 32) & 15];
+    else if constexpr (NS == 52) return x < 32 ? a[x & 31] : (x < 48 ? b[(x - 32) & 15] : c[(x - 48) & 3]);
+    else return x < 32 ? a[x & 31] : b[(x - 32) & 31];
+}
+
+struct IBest {
+    int G, W;   // candidate value; predecessor's packed word
+};
+
+// wave-uniform lane masks carried through the scan (scalar registers, no VALU work)
+struct ScanMasks {
+    unsigned long long tie;      // lanes whose running minimum is shared by two candidates
+    unsigned long long stHave;   // lanes that met their (i-1, j-1) predecessor
+};
+
+// Smallest value over the lanes of the wave for 0 <= v < 64: bisection on ballots (no LDS traffic).
+__device__ __forceinline__ int wave_min_64(int v)
+{
+    int lo = 0;   // answer is in [lo, lo + span)
+#pragma unroll
+    for (int span = 32; span > 0; span >>= 1) {
+        const bool below = v < lo + span;
+        lo += __builtin_amdgcn_ballot_w64(below) ? 0 : span;
+    }
+    return lo;
+}
+
+// why a pair is not answered here (bit mask; statistics in IntArgs::reasons)
+enum : int {
+    kDeferTm = 1,        // maxTM: the two quotients agree to 1e-9
+    kDeferLoopEq = 2,    // best loop candidate ties with the cell's stack / start value
+    kDeferLoopTie = 4,   // two loop candidates tie for the minimum
+    kDeferBad = 8,       // the minimum has H > 0 and S > 0 (thal.c would reject it)
+    kDeferPick = 16,     // two cells tie in the terminal pick
+    kDeferReplay = 32,   // replayed enthalpy differs from the tracked one (never expected)
+    kDeferPathTie = 64,  // a cell of the optimal path has an equal-valued alternative
+};
+
+struct IntResult {
+    PairResult r;
+    int defer;   // not answered here: OR of the reasons above
+};
+
+struct IntArgs {
+    FastArgs f;
+    const IntTables *it;
+    unsigned long long *reasons;   // optional statistics: [0] pairs handed on, [1 + b] reason bit b (b < 7),
+                                   // [8] samples kept, [9 ... 1032] samples; the list mode counts at
+                                   // [1033 ...] (same layout, no samples)
+    int stat_off;                  // 0 (matrix mode) or 1033 (list mode)
+    unsigned *work_counter;        // matrix mode: next work item (one row x 64 sorted columns), zero at launch
+};
+
+// A list entry whose pair needs the f64 kernels (an exact tie was met) carries this bit in .x;
+// entries without it only left their wave because of their table size and may be retried here.
+constexpr unsigned kNeedsF64 = 0x80000000u;
+
+}  // namespace
+
+}  // namespace msspe

@@ -90,16 +90,21 @@ hipError_t launch_pairs_wide(const PairKernelArgs &a, const uint2 *in_list,
 // Exact-integer first stage (thal_pairs_int.hip): same contract as launch_pairs_fast; pairs it does
 // not answer (ties, oversized tables) are appended to a.overflow_list.  reasons: optional device
 // counters [8] ([0] = pairs handed on because of a tie, [1 + b] = reason bit b, see the kernel).
-hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons,
+hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
                             hipStream_t stream);
+// The same stage for oligos of up to pairs_row_max_k() bases (thal_pairs_row.hip): a block works on one
+// row primer at a time and folds everything the loop terms take from that primer into its LDS table.
+hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
+                            hipStream_t stream);
+int pairs_row_max_k();
 // List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit
 // 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
-                                 const uint32_t *in_count, unsigned long long *reasons, hipStream_t stream);
+                                 const uint32_t *in_count, unsigned long long *reasons, int n_cu, hipStream_t stream);
 // Long oligos (17 .. SplitTables::max_k bases, thal_pairs_split.hip): exact-integer first stage with
 // a pair's table split over 2, 4 or 8 lanes; same contract as launch_pairs_int (a.ft is not used).
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
-                              hipStream_t stream);
+                              int lanes, hipStream_t stream);
 int pairs_split_lanes(int k);
 // f64 DP with one wave per pair (thal_pairs_wave.hip), oligos up to st->f64_max_k bases.  in_list:
 // explicit pairs (count *in_count, at most a.overflow_cap); nullptr: the block rows [a.row0, a.row1) x

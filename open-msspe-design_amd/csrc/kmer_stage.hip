@@ -664,7 +664,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     constexpr int kBatch = 32;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    bool use_graph = std::getenv("MSSPE_NO_GRAPH") == nullptr;   // testing aid: plain launches
+    bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
     if (use_graph) {
         // capture on a private stream so that the caller's stream may be of any kind
         hipStream_t cs = nullptr;

@@ -26,10 +26,12 @@ public:
                  const uint64_t *fwd_words, int n_fwd, const uint64_t *rev_words, int n_rev,
                  uint8_t *hit_out, hipStream_t stream, std::string &err);
     void release();
+    void set_use_graph(bool on) { use_graph_ = on; }
 
 private:
     void *buf_[16] = {};
     size_t cap_[16] = {};
+    bool use_graph_ = true;
     int ensure(int slot, size_t bytes, std::string &err);
 };
 

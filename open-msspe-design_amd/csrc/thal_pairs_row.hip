@@ -1,0 +1,612 @@
+// thal_pairs_row.hip -- all-pairs cross-dimer kernel, exact-integer DP, matrix mode for oligos of up
+// to 13 bases with the loop table SPECIALISED TO THE BLOCK'S ROW PRIMER.
+//
+// Same job, same recurrence, same exactness argument and same outputs as thal_pairs_int.hip (the
+// reference's "format N^2 lines -> ntthal -> parse" loop, /root/reference/od-msspe/src/delta_g.rs:61-153;
+// Primer3 2.6.1 thal() restated from SURVEY.md Appendix C.3).  What changes is the price of one
+// predecessor visit, which is what the kernel is made of (about 1,000 lock-step visits per pair):
+//
+//   * gfx950 issues v_add / v_sub / v_and / v_or / v_lshr / v_mov at one wave-instruction per ~2.4
+//     cycles per SIMD, and everything else the scan needs (v_cndmask, v_cmp, v_min, v_add3, v_bfe,
+//     v_lshl_or, SDWA forms) at one per ~4.3 cycles (tools/valu_peak.hip, profiles/r02_valu_peak.txt).
+//     The general visit of thal_pairs_int.hip spends 16 (far) to 24 (near) mostly half-rate
+//     instructions, most of them on classifying the loop (bulge / 1 x 1 / interior, which cell-side
+//     term, which table column) from the coordinates of cell and predecessor.
+//   * A work item here is one ROW primer x a segment of the composition-sorted columns, processed by
+//     the twelve waves of one block.  Every lane of the block shares oligo 1, so everything a loop
+//     term takes from oligo 1 -- the predecessor's pair and its 3' neighbour, the cell's pair and its
+//     5' neighbour, hence the kind-specific tables AND the cell-side term of every loop kind whose
+//     cell-side term does not need a base of oligo 2 that the predecessor does not already carry --
+//     is folded into a table T[l2][i][i - ii][n2] built in LDS per row (37 KB, rebuilt in ~2 us
+//     from the chemistry's general table).  A slot word carries the predecessor's coordinates as
+//     K = 772 jj + 4 ii + n2  (n2 = the base of oligo 2 right of the predecessor), so that ONE
+//     subtraction from a per-cell constant yields the table index:
+//         C - K = 772 (j - 1 - jj) + 4 (14 i + (i - ii)) + (3 - n2)
+//     A predecessor right of the cell (j - 1 - jj < 0) makes the 17-bit field wrap and an unsigned min
+//     clamps it onto a "not available" entry: no validity test, no loop classification, no column
+//     fix-up.  772 = 4 (mod 64): the 64 lanes of a wave sit on nearly the same rows (same slot number),
+//     what differs between them is l2 and n2, and with this stride the 48 (l2, n2) combinations fall
+//     into 48 different LDS banks (a power-of-two layout puts them all into one: measured 16-way
+//     conflicts, the kernel then gains 4 % instead of 30 %).
+//     What is left of the classification is one select: the cell-side mismatch term of an interior
+//     loop with l2 >= 2 needs the base left of the cell on oligo 2, which only the lane knows; the
+//     table marks the entries that must NOT get it by a 2^28 offset.
+//   * far visit (predecessor known to lie three or more rows up):  sub, lshr, min, [ds_read], cmp,
+//     cndmask, add3, cmp, cmp, cndmask, min = 2 full-rate + 8 half-rate instructions (16 before);
+//     near visit: + cmp, 2 x cndmask that catch the cell (i-1, j-1) for maxTM.
+//
+// Ties, maxTM, the terminal pick, the traceback by pointer and the f64 replay of the optimal path are
+// those of thal_pairs_int.hip; a pair this kernel does not answer goes to the same hand-over list.
+#include "int_core.hpp"
+
+namespace msspe {
+
+namespace {
+
+constexpr int kRowK = 13;                        // longest oligo of this kernel
+constexpr int kRowThreads = 768, kRowSlots = 52;
+constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. 11
+constexpr int kRowA = 772;                       // stride of l2: 4 * 14 * 13 = 728 entries used, = 4 (mod 64)
+constexpr int kRowTEntries = kRowL2 * kRowA;
+constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
+constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
+constexpr int kNoY = 1 << 28;                    // table entries at or above kNoY / 2 carry this offset: no cell-side term
+constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
+// slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
+//             bits 14..0   h + kHBias
+constexpr int kEmptyRowW = ((15 * kRowA) << 17) | kHBias;  // jj = 15: right of every cell
+
+// Order matters: LDS instructions take a 16-bit immediate offset, so everything that is addressed as
+// "lane + constant" or "table + index" lives in the first 64 KB and needs no address arithmetic.
+struct SharedRow {
+    int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
+    // per-lane state that is touched once per cell (registers are the scarce resource: 104 of a lane's
+    // 168 hold the table, and what does not fit goes to scratch memory, i.e. to HBM latency)
+    int pick[3][kRowThreads];           // terminal pick: value, word, number of later cells with the same value
+    unsigned soft[2][kRowThreads];      // slots whose value has an equal-valued alternative (bit mask)
+    int yts[64];                        // [i][m2]: cell-side mismatch term of an interior loop, G units
+    int g[FastTables::kCount];
+    Lds F;                              // f64 S + int H (replay, end terms)
+    double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
+    unsigned char pred[kRowSlots][kRowThreads];
+    unsigned short path[kPathMax][kRowThreads];
+    unsigned next_group;
+    int item;
+};
+
+struct KParts {
+    int ii, jj, n2;
+};
+// K = 772 jj + 4 ii + n2 (K < 2^14): jj = K / 772 by multiplication (exact for every K < 16384)
+__device__ __forceinline__ KParts k_parts(unsigned K)
+{
+    KParts p;
+    p.jj = (int)((K * 21733u) >> 24);
+    const unsigned rest = K - (unsigned)p.jj * (unsigned)kRowA;
+    p.ii = (int)(rest >> 2);
+    p.n2 = (int)(rest & 3u);
+    return p;
+}
+// coordinates of a slot word as one byte jj << 4 | ii (0xff: none)
+__device__ __forceinline__ int word_cw(int W)
+{
+    const KParts p = k_parts((unsigned)W >> 17);
+    return (p.jj << 4) | p.ii;
+}
+// what the traceback compares: K without n2
+__device__ __forceinline__ unsigned word_sig(int W) { return ((unsigned)W >> 17) & ~3u; }
+__device__ __forceinline__ unsigned sig_of_cw(int cw) { return (unsigned)(cw >> 4) * (unsigned)kRowA + (unsigned)((cw & 15) << 2); }
+__device__ __forceinline__ int word_h(int W) { return (W & 0x7fff) - kHBias; }
+// the f64 kernels' word (h << 14 | po << 8 | im1 << 4 | jm1) of pair_core.hpp's cand_* helpers;
+// po = pair base | 3' neighbour on oligo 1 << 2 | right neighbour on oligo 2 << 4
+__device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
+{
+    const KParts p = k_parts(K);
+    const int po = (int)((s1 >> (2 * p.ii)) & 15u) | (p.n2 << 4);
+    return (h << 14) | (po << 8) | (p.ii << 4) | p.jj;
+}
+__device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
+
+// The lane's bit of a wave-uniform 64-bit mask (a ballot result): the mask IS a lane predicate, so one
+// v_cndmask reads it; shifting it by the lane number costs a 64-bit shift and a live register pair.
+__device__ __forceinline__ bool lane_bit(unsigned long long m)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+    return r != 0;
+}
+
+struct RCell {
+    unsigned C;     // per-cell minuend of the address subtraction
+    int yTS;        // cell-side mismatch term of an interior loop with l2 >= 2
+    int idxStk;     // table address that the cell (i-1, j-1) produces
+};
+
+template <int NS, int PC = 0>
+__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int far_upto, const char *T,
+                                              const RCell &c, IBest &best, IBest &stk, ScanMasks &m)
+{
+    if constexpr (PC * kC < NS) {
+        if (PC * kC < upto) {   // wave-uniform
+            unsigned idx[kC];
+            int t[kC];
+            if (PC * kC + kC <= far_upto) {   // wave-uniform: every lane has these slots >= 3 rows up
+                asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
+#pragma unroll
+                for (int e = 0; e < kC; ++e)
+                    idx[e] = min((c.C - (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e)) >> 15, (unsigned)kRowTBytes);
+#pragma unroll
+                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + idx[e]);
+#pragma unroll
+                for (int e = 0; e < kC; ++e) {
+                    const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
+                    const int y = t[e] >= kNoY / 2 ? -kNoY : c.yTS;
+                    const int cand = t[e] + y + Gp;   // unavailable: kBig + ..., never below best.G <= kValid
+                    const bool better = cand < best.G;
+                    const bool eq = cand == best.G;
+                    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
+                    best.G = better ? cand : best.G;
+                    best.W = better ? Wp : best.W;
+                }
+            } else {
+                asm volatile("" ::"n"(PC + 64));
+#pragma unroll
+                for (int e = 0; e < kC; ++e)
+                    idx[e] = min((c.C - (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e)) >> 15, (unsigned)kRowTBytes);
+#pragma unroll
+                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + idx[e]);
+#pragma unroll
+                for (int e = 0; e < kC; ++e) {
+                    const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
+                    const int y = t[e] >= kNoY / 2 ? -kNoY : c.yTS;
+                    const int cand = t[e] + y + Gp;
+                    const bool better = cand < best.G;
+                    const bool eq = cand == best.G;
+                    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
+                    best.G = better ? cand : best.G;
+                    best.W = better ? Wp : best.W;
+                    const bool isstk = idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
+                    stk.G = isstk ? Gp : stk.G;
+                    stk.W = isstk ? Wp : stk.W;
+                    m.stHave |= __builtin_amdgcn_ballot_w64(isstk);
+                }
+            }
+            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, far_upto, T, c, best, stk, m);
+        }
+    }
+}
+
+// thal ANY for the lane's pair (oligo 1 = the block's row primer).  n_cells == 0: idle lane.
+template <int NS>
+__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const SeqPair &q,
+                                                  unsigned rowmask, int n_cells, int nmax)
+{
+    const Lds &F = sh.F;
+    v32i Ga = 0, Wa = kEmptyRowW;
+    typename TabTypes<NS>::B Gb = 0, Wb = kEmptyRowW;
+    typename TabTypes<NS>::C Gc = 0, Wc = kEmptyRowW;
+    int defer = 0;
+    CellCtx c;
+    c.rS = 0.0;
+    c.rH = 0;
+    c.im1p = c.jm1p = 0;
+    c.yTS = c.yMM = c.bBase = 0;
+    unsigned Rrem = rowmask, mrem = 0;
+    int im1 = 0, jm1 = 0;
+    // first slot of the lane's current row and of its two previous non-empty rows: every slot
+    // below row_lo2 lies at least three rows above the current cell
+    int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
+    sh.pick[0][threadIdx.x] = 0x7fffffff;   // pickG
+    sh.pick[1][threadIdx.x] = 0;            // pickW
+    sh.pick[2][threadIdx.x] = 0;            // nTie
+    sh.soft[0][threadIdx.x] = sh.soft[1][threadIdx.x] = 0u;
+
+    for (int slot_ = 0; slot_ < nmax; ++slot_) {
+        const int slot = __builtin_amdgcn_readfirstlane(slot_);
+        // ---- next complementary cell in row-major order
+        const bool newrow = mrem == 0;
+        const int t = __ffs((int)Rrem) - 1;
+        const int a_new = (q.s1 >> (t & 31)) & 3;
+        const unsigned m_new = spaced_mask(q.s2, 3 - a_new, q.lenmask);
+        im1 = newrow ? (t >> 1) : im1;
+        row_lo2 = newrow ? row_lo1 : row_lo2;
+        row_lo1 = newrow ? row_lo0 : row_lo1;
+        row_lo0 = newrow ? slot : row_lo0;
+        Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
+        mrem = newrow ? m_new : mrem;
+        jm1 = (__ffs((int)mrem) - 1) >> 1;
+        mrem &= mrem - 1;
+        im1 &= 15;
+        jm1 &= 15;
+        RCell rc;
+        rc.C = ((unsigned)((jm1 - 1) * kRowA + im1 * 60 + 3) << 17) | 0x7fffu;
+        // m2 = base left of the cell on oligo 2 (0 in column 0, where no loop can close)
+        rc.yTS = sh.yts[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)];
+        rc.idxStk = ((im1 * 14 + 1) * 4 + (int)((q.s1 >> (2 * im1)) & 3u)) * 4;   // l2 = 0, i - ii = 1, 3 - n2 = base of the cell
+        // ---- all earlier slots as predecessors
+        IBest best, stk;
+        best.G = IntTables::kValid;
+        best.W = 0;
+        stk.G = stk.W = 0;
+        ScanMasks sm;
+        sm.tie = sm.stHave = 0ull;
+        const int far_upto = wave_min_64(slot < n_cells ? row_lo2 : 63);
+        scan_fill_row<NS>(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, rc, best, stk, sm);
+        const bool tie = lane_bit(sm.tie);
+        const bool stHave = lane_bit(sm.stHave);
+        const CellBases b = cell_bases(q, im1, jm1, c);   // after the scan: nothing of it is live across it
+        // ---- thal.c maxTM(): helix extension if it raises Tm (see thal_pairs_int.hip)
+        int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
+        if (stHave) {
+            const int rH = F.H[b.idxR];
+            const double cq = sh.cq[b.idxR - FastTables::kEndR];
+            const int H1 = word_h(stk.W) * 10 + F.H[b.wc];
+            const int G1 = stk.G + sh.g[b.wc];
+            const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
+            const double B0 = (double)(2000 * H0 - G0) + cq, B1 = (double)(2000 * H1 - G1) + cq;
+            const double lhs = A1 * B0, rhs = A0 * B1;
+            const bool sure = (B0 < 0.0) & (B1 < 0.0) & (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
+            flags |= sure ? 0 : kDeferTm;
+            if (lhs > rhs) {
+                H0 = H1;
+                G0 = G1;
+                pred = word_cw(stk.W);
+            }
+        }
+        // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
+        if (best.G <= G0) {
+            // exact enthalpy of the best candidate from the compact tables
+            const CandGeom g = cand_geometry(c, core_word_row(best.W, q.s1));
+            const int Hw = F.H[g.lx] + F.H[g.y] + word_h(best.W) * 10;
+            if (best.G < G0) {
+                flags |= tie ? kDeferLoopTie : 0;
+                flags |= ((Hw > 0) & (2000 * Hw - best.G > -1000)) ? kDeferBad : 0;
+                H0 = Hw;
+                G0 = best.G;
+                pred = word_cw(best.W);
+            } else if (Hw == H0) {
+                if (slot < n_cells) sh.soft[slot >> 5][threadIdx.x] |= 1u << (slot & 31);
+            } else {
+                flags |= kDeferLoopEq;
+            }
+        }
+        const int hb = H0 / 10 + kHBias;
+        flags |= ((unsigned)hb > 0x7fffu) ? kDeferReplay : 0;   // enthalpy beyond the 15-bit field: hand the pair on
+        const int Wcell = (int)((unsigned)(jm1 * kRowA + (im1 << 2) + ((b.po_c >> 4) & 3)) << 17) | (hb & 0x7fff);
+        const bool in = slot < n_cells;   // lanes past their last cell compute garbage
+        defer |= in ? flags : 0;
+        // ---- terminal pick (strict minimum of dG incl. the right end term, first in slot order)
+        {
+            const int Gt = G0 + sh.g[b.idxR];
+            const int pickG = sh.pick[0][threadIdx.x];
+            if (in & (Gt < pickG)) {
+                sh.pick[0][threadIdx.x] = Gt;
+                sh.pick[1][threadIdx.x] = Wcell;
+                sh.pick[2][threadIdx.x] = 0;
+            } else if (in & (Gt == pickG)) {
+                sh.pick[2][threadIdx.x] += 1;
+            }
+        }
+        // ---- publish the cell (idle lanes write a slot nobody reads)
+        if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
+            Ga[slot & 31] = G0;
+            Wa[slot & 31] = Wcell;
+        } else if constexpr (NS == 52) {
+            if (slot < 48) {
+                Gb[(slot - 32) & 15] = G0;
+                Wb[(slot - 32) & 15] = Wcell;
+            } else {
+                Gc[(slot - 48) & 3] = G0;
+                Wc[(slot - 48) & 3] = Wcell;
+            }
+        } else {
+            Gb[(slot - 32) & 15] = G0;
+            Wb[(slot - 32) & 15] = Wcell;
+        }
+        sh.pred[slot][threadIdx.x] = (unsigned char)pred;
+    }
+
+    IntResult out;
+    out.r.none = n_cells == 0;
+    out.r.dG = INFINITY;
+    out.r.t = 0.0;
+    out.r.conflict = false;
+
+    const int nch = (nmax + kC - 1) / kC;
+    defer |= sh.pick[2][threadIdx.x] > 0 ? kDeferPick : 0;   // a second walk would be paid by the whole wave: handed on
+    const unsigned long long softTie =
+        (unsigned long long)sh.soft[0][threadIdx.x] | ((unsigned long long)sh.soft[1][threadIdx.x] << 32);
+
+    // ---- walk from the picked cell: traceback by pointer into the LDS scratch, then replay forwards
+    //      in f64 with Primer3's operation order (fillMatrix / maxTM)
+    double S = 0.0;
+    int H = 0, P = 0, dpath = 0;
+    const int endW = sh.pick[1][threadIdx.x];
+    {
+        unsigned cur = word_sig(endW);
+        bool done = out.r.none;
+        for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
+            const int pc = __builtin_amdgcn_readfirstlane(pc_);
+            int W[kC];
+#pragma unroll
+            for (int e = 0; e < kC; ++e) W[e] = slot_of<NS>(Wa, Wb, Wc, pc * kC + e);
+#pragma unroll
+            for (int e = kC - 1; e >= 0; --e) {
+                const int slot = pc * kC + e;
+                const int pr = sh.pred[slot][threadIdx.x];
+                const bool hit = !done & (slot < n_cells) & (word_sig(W[e]) == cur);
+                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)((unsigned)W[e] >> 17);
+                dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
+                P += hit ? 1 : 0;
+                cur = hit ? sig_of_cw(pr) : cur;
+                done = done | (hit & (pr == 0xff));
+            }
+        }
+    }
+    {
+        int prevCore = 0;
+        const int maxP = wave_max(P);
+        for (int step_ = 0; step_ < maxP; ++step_) {
+            const int step = __builtin_amdgcn_readfirstlane(step_);
+            const int e = P - 1 - step;
+            if (e >= 0) {
+                const int core = core_of_k(sh.path[e & (kPathMax - 1)][threadIdx.x], q.s1, 0);
+                CellCtx cc;
+                const CellBases b = cell_bases(q, (core >> 4) & 15, core & 15, cc);
+                if (step == 0) {
+                    S = F.S[b.idxL];
+                    H = F.H[b.idxL];
+                } else if (((core & 0xff) - (prevCore & 0xff)) == 0x11) {   // the cell (i-1, j-1): stacked pair
+                    S = S + F.S[b.wc];
+                    H = H + F.H[b.wc];
+                } else {
+                    const CandGeom g = cand_geometry(cc, prevCore);
+                    const CandLoad v = cand_gather(F, g);
+                    S = ((v.sLX + v.sY) + v.sZ) + S;
+                    H = v.hLX + v.hY + H;
+                }
+                prevCore = core;
+            }
+        }
+    }
+    // the replayed enthalpy must be the tracked one; anything else is handed on
+    dpath |= (!out.r.none & (H != word_h(endW) * 10)) ? kDeferReplay : 0;
+    defer |= dpath;
+    // ---- thal.c drawDimer(): totals
+    {
+        const KParts pe = k_parts((unsigned)endW >> 17);
+        CellCtx cc;
+        const CellBases b = cell_bases(q, pe.ii, pe.jj, cc);
+        const double rS = F.S[b.idxR];
+        const int rH = F.H[b.idxR];
+        const double dH = (double)(H + rH + 200);
+        const double dS = (S + rS) + K.init_S;
+        const int N = P - 1;
+        const double t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
+        const double G = dH - (K.temp_k * (dS + (N * K.salt)));
+        if (!out.r.none) {
+            out.r.dG = G;
+            out.r.t = t;
+            out.r.conflict = G <= K.g_cut;
+        }
+    }
+    out.defer = out.r.none ? 0 : defer;
+    return out;
+}
+
+// One lock-step DP of the wave: lane = (row, col), all lanes share `row`.
+template <int NS>
+__device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, int row, int col, uint64_t pa,
+                                               uint64_t pb, bool inside)
+{
+    const int lane = threadIdx.x & 63;
+    SeqPair q;
+    unsigned rowmask;
+    int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
+    q.s1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.s1);   // the block's row primer: a scalar
+    const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
+    bool spill = inside & ((n_cells > NS) | sym);
+    unsigned flag = 0u;
+    if (!inside | spill) n_cells = 0;
+    int nmax = wave_max(n_cells);
+    // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes far above
+    // the rest (mixed compositions at bin boundaries) are cheaper in a sorted list stage.
+    for (int round = 0; round < 6; ++round) {
+        const int next = wave_max(n_cells < nmax ? n_cells : 0);
+        const int m = __popcll(__ballot(n_cells == nmax));
+        if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
+        if (n_cells == nmax) {
+            spill = true;
+            n_cells = 0;
+        }
+        nmax = next;
+    }
+    if (nmax == 0) {   // wave-uniform: nothing to compute
+        if (spill) {
+            const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
+            if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
+        }
+        return;
+    }
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const bool deferred = inside & !spill & (r.defer != 0);
+    if (deferred) flag = kNeedsF64;
+    spill |= deferred;
+    if (spill) {
+        const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
+        if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
+    }
+    if (a.reasons) {
+        const unsigned long long dm = __ballot(deferred);
+        if (dm) {   // wave-uniform
+            if (lane == 0) atomicAdd(&a.reasons[a.stat_off], (unsigned long long)__popcll(dm));
+#pragma unroll
+            for (int bit = 0; bit < 7; ++bit) {
+                const unsigned long long bm = __ballot(deferred & ((r.defer >> bit) & 1));
+                if (lane == 0 && bm) atomicAdd(&a.reasons[a.stat_off + 1 + bit], (unsigned long long)__popcll(bm));
+            }
+            // a few samples for diagnostics: row << 40 | col << 16 | reasons
+            if (deferred && a.stat_off == 0 && a.reasons[8] < 1024ull) {
+                const unsigned long long at = atomicAdd(&a.reasons[8], 1ull);
+                if (at < 1024ull)
+                    a.reasons[9 + at] = ((unsigned long long)row << 40) | ((unsigned long long)col << 16) |
+                                        (unsigned long long)r.defer;
+            }
+        }
+    }
+    // ---- sinks (conflicts are rare: one atomic OR per conflicting pair, one add per wave)
+    const bool live = inside & !spill;
+    const bool hit = live & r.r.conflict;
+    const size_t orow = (size_t)(row - a.f.sinks.row0);
+    const size_t ocol = (size_t)(col - a.f.sinks.col0);
+    if (hit && a.f.sinks.bitmap)
+        atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
+                 1ull << (ocol & 63));
+    if (a.f.sinks.row_conflicts) {
+        const unsigned long long bits = __ballot(hit);
+        if (lane == 0 && bits) atomicAdd(&a.f.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+    }
+    if (live) {
+        if (a.f.sinks.dg) a.f.sinks.dg[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.dG;
+        if (a.f.sinks.tm) a.f.sinks.tm[orow * (size_t)a.f.sinks.ncols + ocol] = r.r.t;
+    }
+}
+
+// The loop table of row primer s1 (2 bits per base): for every (l2, i, r = i - ii, n2) the loop term of
+// the general table (fast_tables.hpp IntTables::T, row d = 16 l1 + l2, l1 = r - 1) with the column that
+// oligo 1 determines, plus the cell-side term where it needs no base of oligo 2 beyond n2:
+//   bulges          column a_p | a_c << 2 (the general table holds both closing pairs)
+//   l2 == 1         the base between predecessor and cell on oligo 2 IS n2: 1 x 1 loops get their
+//                   cell-side mismatch, interior loops their cell-side terminal mismatch
+//   l2 >= 2, r >= 2 pred side only; the lane adds yts[i][m2].  Every other entry carries + kNoY.
+// r == 0 (same row), ii < 0, the stacked pair and loops the chemistry has no entry for: kBig (+ kNoY).
+__device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a, unsigned s1)
+{
+    const int32_t *Tg = a.it->T;
+    for (int e = threadIdx.x; e < kRowTEntries; e += kRowThreads) {
+        const int l2 = e / kRowA, rem = e - l2 * kRowA;
+        const int n2 = 3 - (rem & 3), ir = rem >> 2, i = ir / 14, r = ir - i * 14;
+        const int ii = i - r, l1 = r - 1;
+        int v = IntTables::kBig;
+        bool needs_y = false;
+        if (r >= 1 && ii >= 0 && i < a.f.k && (l1 | l2) != 0 && l1 <= IntTables::kMaxL) {
+            const int d = l1 * 16 + l2;
+            const int a_p = (int)((s1 >> (2 * ii)) & 3u), a_c = (int)((s1 >> (2 * i)) & 3u);
+            if (l1 == 0 || l2 == 0) {
+                v = Tg[d * 64 + (a_p | (a_c << 2))];
+            } else {
+                const int n1 = (int)((s1 >> (2 * ii + 2)) & 3u);
+                v = Tg[d * 64 + (a_p | (n1 << 2) | (n2 << 4))];
+                if (l2 == 1) {
+                    const int m1 = (int)((s1 >> (2 * i - 2)) & 3u);
+                    const int ci = ((3 - a_c) * 4 + n2) * 4 + m1;
+                    const int y = sh.g[(d == 0x11 ? FastTables::kMMc : FastTables::kTSc) + ci];
+                    v = (v >= IntTables::kValid || y >= IntTables::kValid) ? IntTables::kBig : v + y;
+                } else {
+                    needs_y = v < IntTables::kValid;
+                }
+            }
+        }
+        sh.T[e] = needs_y ? v : v + kNoY;
+    }
+    if (threadIdx.x < 4) sh.T[kRowTEntries + threadIdx.x] = IntTables::kBig + kNoY;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
+        const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
+        sh.yts[threadIdx.x] = sh.g[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+    }
+}
+
+template <int NS>
+__global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
+{
+    __shared__ SharedRow sh;
+    for (int e = threadIdx.x; e < FastTables::kCount; e += kRowThreads) {
+        sh.F.S[e] = a.f.ft->S[e];
+        sh.F.H[e] = a.f.ft->H[e];
+        sh.g[e] = a.it->g[e];
+    }
+    for (int e = threadIdx.x; e < 100; e += kRowThreads)
+        sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
+    const int lane = threadIdx.x & 63;
+    const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
+    const int n_seg = (ncolg + kSegGroups - 1) / kSegGroups;
+    const unsigned n_items = (unsigned)n_seg * (unsigned)(a.f.row1 - a.f.row0);
+    int built_row = -1;
+    // Work items (one row x up to kSegGroups column groups) are handed to the BLOCKS from a counter; inside
+    // an item the column groups are handed to the waves from a counter in LDS, so that a block's
+    // waves need not march together (the cost of a group varies with its compositions).
+    for (;;) {
+        if (threadIdx.x == 0) {
+            sh.item = (int)atomicAdd(a.work_counter, 1u);
+            sh.next_group = 0u;
+        }
+        __syncthreads();
+        const unsigned item = (unsigned)sh.item;
+        if (item >= n_items) break;   // block-uniform
+        const int row = a.f.row0 + (int)(item / (unsigned)n_seg), seg = (int)(item % (unsigned)n_seg);
+        const uint64_t pa = a.f.pool[row];
+        if (row != built_row) {
+            const unsigned lenmask = (1u << (2 * a.f.k)) - 1u;
+            build_row_table(sh, a, (unsigned)pa & lenmask);
+            built_row = row;
+        }
+        __syncthreads();
+        const unsigned g_lo = (unsigned)seg * kSegGroups;
+        const unsigned g_hi = min((unsigned)ncolg, g_lo + (unsigned)kSegGroups);
+        for (;;) {
+            unsigned grp = 0;
+            if (lane == 0) grp = atomicAdd(&sh.next_group, 1u);
+            grp = g_lo + (unsigned)__builtin_amdgcn_readfirstlane((int)grp);
+            if (grp >= g_hi) break;   // wave-uniform
+            const int cq = a.f.col0 + (int)grp * 64 + lane;
+            const bool inside = cq < a.f.col1;
+            const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
+            const int col = (int)a.f.perm[inside ? cq : a.f.col0];
+            wave_pairs_row<NS>(sh, a, row, col, pa, pb, inside);
+        }
+        __syncthreads();   // every wave is done with the table (and with sh.item) before the next item
+    }
+}
+
+}  // namespace
+
+int pairs_row_max_k() { return kRowK; }
+
+hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
+                            hipStream_t stream)
+{
+    if (a.k > kRowK || a.k < 2) return hipErrorInvalidValue;
+    IntArgs x;
+    FastArgs &f = x.f;
+    f.ft = a.ft;
+    f.c = a.c;
+    f.pool = a.pool;
+    f.cols_sorted = a.cols_sorted;
+    f.perm = a.perm;
+    f.k = a.k;
+    f.row0 = a.row0;
+    f.row1 = a.row1;
+    f.col0 = a.col0;
+    f.col1 = a.col1;
+    f.sinks = a.sinks;
+    f.ovf_list = a.overflow_list;
+    f.ovf_count = a.overflow_count;
+    f.ovf_cap = a.overflow_cap;
+    f.in_list = nullptr;
+    f.in_count = nullptr;
+    x.it = it;
+    x.reasons = reasons;
+    x.stat_off = 0;
+    x.work_counter = a.work_counter;
+    const long ncolg = (a.col1 - a.col0 + 63) / 64;
+    const long items = ((ncolg + kSegGroups - 1) / kSegGroups) * (long)(a.row1 - a.row0);
+    if (items <= 0) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
+    // one persistent block per CU (about 153 KB of LDS each)
+    const int grid = (int)(items < (long)n_cu ? items : (long)n_cu);
+    hipLaunchKernelGGL((k_pairs_row<kRowSlots>), dim3(grid), dim3(kRowThreads), 0, stream, x);
+    return hipGetLastError();
+}
+
+}  // namespace msspe

@@ -544,18 +544,10 @@ __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
 
 }  // namespace
 
-int pairs_split_lanes(int k)
-{
-    if (const char *e = std::getenv("MSSPE_SPLIT_LANES")) {   // experiment switch
-        if (e[0] == '2') return 2;
-        if (e[0] == '4') return 4;
-        if (e[0] == '8') return 8;
-    }
-    return k <= 20 ? 2 : (k <= 28 ? 4 : 8);
-}
+int pairs_split_lanes(int k) { return k <= 20 ? 2 : (k <= 28 ? 4 : 8); }
 
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
-                              hipStream_t stream)
+                              int lanes, hipStream_t stream)
 {
     SplitArgs x;
     x.st = st;
@@ -575,7 +567,7 @@ hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, un
     x.reasons = reasons;
     x.work_counter = a.work_counter;
     if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
-    const int Q = pairs_split_lanes(a.k);
+    const int Q = (lanes == 2 || lanes == 4 || lanes == 8) ? lanes : pairs_split_lanes(a.k);   // option "split_lanes"
     const long tiles = (long)((a.col1 - a.col0 + 64 / Q - 1) / (64 / Q)) * (long)((a.row1 - a.row0 + 7) / 8);
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L ? tiles : 256L);   // one persistent block per CU (about 150 KB of LDS)

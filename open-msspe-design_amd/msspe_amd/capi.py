@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     L.msspe_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
     L.msspe_destroy.argtypes = [vp]
     L.msspe_set_stream.argtypes = [vp, vp]
+    L.msspe_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.msspe_reset_stream.argtypes = [vp]
     L.msspe_synchronize.argtypes = [vp]
     L.msspe_pack_oligos.argtypes = [C.c_char_p, C.c_int, C.c_int, u64p]
@@ -188,6 +189,10 @@ class Engine:
     def set_stream(self, hip_stream: int | None):
         """Run on the caller's HIP stream (raw handle; 0/None = HIP's default stream)."""
         self._check(self.L.msspe_set_stream(self.ptr, C.c_void_p(hip_stream or 0)))
+
+    def set_option(self, key: str, value) -> None:
+        """Engine option (include/msspe_hip.h msspe_set_option); the library never reads the environment."""
+        self._check(self.L.msspe_set_option(self.ptr, key.encode(), str(value).encode()))
 
     def reset_stream(self):
         self._check(self.L.msspe_reset_stream(self.ptr))

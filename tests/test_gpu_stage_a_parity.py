@@ -126,9 +126,12 @@ def test_rows_uploaded_through_pinned_staging(eng, m, oracle):
 
 def test_plain_launches_instead_of_graph_replays(eng, m, oracle, monkeypatch):
     """The greedy loop's fallback when hipGraph capture is not available."""
-    monkeypatch.setenv("MSSPE_NO_GRAPH", "1")
-    seqs = [bytes(r).decode() for r in m.synth.aligned_genomes(30, 4000)]
-    run_both(eng, m, oracle, seqs, mm=2)
+    eng.set_option("stage_a_graph", 0)
+    try:
+        seqs = [bytes(r).decode() for r in m.synth.aligned_genomes(30, 4000)]
+        run_both(eng, m, oracle, seqs, mm=2)
+    finally:
+        eng.set_option("stage_a_graph", 1)
 
 
 def test_long_posting_lists_and_ties(eng, m, oracle):

@@ -190,8 +190,7 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k
     21-mers through the split-table kernel and, with that one switched off, through the matrix mode
     of the one-wave-per-pair kernel."""
     import torch
-    if no_split:
-        monkeypatch.setenv("MSSPE_SPLIT_MIN_K", "99")
+    eng.set_option("split_min_k", 99 if no_split else 15)
     n = 200
     pool_ascii = m.synth.random_pool(n, k, seed=78)
     d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
@@ -206,6 +205,7 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k
         torch.cuda.synchronize()
     finally:
         eng.reset_stream()
+        eng.set_option("split_min_k", 15)
     _, dg, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii)
     np.testing.assert_array_equal(d_dg.cpu().numpy(), dg[r0:r1, c0:c1])
     want = np.zeros(n, dtype=np.int64)
@@ -220,7 +220,7 @@ def test_large_pool_properties(eng, m, oracle, oracle_tables, monkeypatch):
     entries so that the stages behind the first one run twice mid-screen): size-independent
     properties of the counts/bitmap outputs plus an oracle check of sampled rows."""
     import torch
-    monkeypatch.setenv("MSSPE_LIST_CAP_LOG2", "27")
+    eng.set_option("list_cap_log2", 27)
     n = 16384
     pool_ascii = m.synth.random_pool(n, 13)
     d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
@@ -233,6 +233,7 @@ def test_large_pool_properties(eng, m, oracle, oracle_tables, monkeypatch):
         torch.cuda.synchronize()
     finally:
         eng.reset_stream()
+        eng.set_option("list_cap_log2", 0)
     rc = d_rc.cpu().numpy().astype(np.int64)
     bits = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), axis=1, bitorder="little")
     # (1) the per-row counts are the popcounts of the bitmap rows
@@ -256,19 +257,29 @@ def test_large_pool_properties(eng, m, oracle, oracle_tables, monkeypatch):
 
 def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypatch):
     """The exact-integer first stage (default) and the f64 register-table kernel
-    (MSSPE_PAIR_KERNEL=f64) must produce the same doubles and the same decisions; the integer
+    (option pair_kernel = f64) must produce the same doubles and the same decisions; the integer
     stage may hand only a small share of the pairs on, for the documented reasons."""
     pool = m.synth.pool_strings(m.synth.random_pool(700, 13, seed=77))
     chem = m.Chem.ntthal()
     eng.pair_stage_stats()
     a = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
     stats = eng.pair_stage_stats()
-    monkeypatch.setenv("MSSPE_PAIR_KERNEL", "f64")
-    b = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
-    assert eng.pair_stage_stats()["deferred"] == 0          # the integer stage did not run
-    monkeypatch.delenv("MSSPE_PAIR_KERNEL")
+    eng.set_option("pair_kernel", "f64")
+    try:
+        b = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+        assert eng.pair_stage_stats()["deferred"] == 0          # the integer stage did not run
+        # the general integer kernel (what 14..16-mers and the list mode run) as the first stage
+        eng.set_option("pair_kernel", "int")
+        c = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+        stats_general = eng.pair_stage_stats()
+    finally:
+        eng.set_option("pair_kernel", "auto")
     for key in ("dg", "tm", "bitmap", "row_conflicts"):
         np.testing.assert_array_equal(a[key], b[key])
+        np.testing.assert_array_equal(a[key], c[key])
+    # the row-specialised kernel and the general one hand on the same pairs for the same reasons
+    flat = lambda d: {k: v for k, v in d.items() if k not in ("list", "needed_f64")}
+    assert flat(stats) == flat(stats_general)
     n2 = len(pool) ** 2
     assert 0 < stats["deferred"] < 0.06 * n2                  # retried in list mode
     assert 0 < stats["needed_f64"] < 0.01 * n2                # what only the f64 kernels can answer
@@ -384,9 +395,9 @@ def test_long_oligo_stage_equals_generic_kernel(m, oracle, oracle_tables, monkey
         fast = e.cross_dimer(pool, chem, -9000.0)
         stats = e.pair_stage_stats()
         handed_on = e.last_overflow_pairs()
-        monkeypatch.setenv("MSSPE_FORCE_GENERIC", "1")
+        e.set_option("force_generic", 1)
         slow = e.cross_dimer(pool, chem, -9000.0)
-        monkeypatch.delenv("MSSPE_FORCE_GENERIC")
+        e.set_option("force_generic", 0)
         np.testing.assert_array_equal(fast["bitmap"], slow["bitmap"])
         np.testing.assert_array_equal(fast["row_conflicts"], slow["row_conflicts"])
         assert fast["row_conflicts"].sum() > 0
