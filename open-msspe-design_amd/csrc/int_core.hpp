@@ -82,6 +82,29 @@ struct ScanMasks {
     unsigned long long stHave;   // lanes that met their (i-1, j-1) predecessor
 };
 
+// The lane's bit of a wave-uniform 64-bit mask (a ballot result): the mask IS a lane predicate, so one
+// v_cndmask reads it; shifting it by the lane number costs a 64-bit shift and a live register pair.
+__device__ __forceinline__ bool lane_bit(unsigned long long m)
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+    return r != 0;
+}
+
+// median of three = the second smallest: with a <= b it keeps the two smallest values seen in (min, med3)
+__device__ __forceinline__ int med3_i32(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// running minimum of the scan: value, the slot word that gave it, and the second smallest value (two
+// candidates tie for the minimum iff G2 == G at the end: no per-visit mask bookkeeping)
+struct RBest {
+    int G, W, G2;
+};
+
 // Smallest value over the lanes of the wave for 0 <= v < 64: bisection on ballots (no LDS traffic).
 __device__ __forceinline__ int wave_min_64(int v)
 {

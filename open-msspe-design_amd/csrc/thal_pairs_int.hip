@@ -107,25 +107,23 @@ __device__ __forceinline__ Visit visit_geometry_far(const ICell &c, int Wp)
     return v;
 }
 
-__device__ __forceinline__ void visit_finish_far(const Visit &v, int t, int Gp, int Wp, IBest &best,
+__device__ __forceinline__ void visit_finish_far(const Visit &v, int t, int Gp, int Wp, RBest &best,
                                                  ScanMasks &m)
 {
     const int cand = t + v.y + Gp;
     const bool better = cand < best.G;
-    const bool eq = cand == best.G;
-    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
-    best.G = better ? cand : best.G;
+    best.G2 = med3_i32(best.G, best.G2, cand);   // second smallest so far: a tie shows as G2 == G at the end
+    best.G = min(cand, best.G);
     best.W = better ? Wp : best.W;
 }
 
-__device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int Wp, IBest &best,
+__device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int Wp, RBest &best,
                                              IBest &stk, ScanMasks &m)
 {
     const int cand = t + v.y + Gp;   // unavailable / invalid: kBig + ..., never below best.G <= kValid
     const bool better = cand < best.G;
-    const bool eq = cand == best.G;
-    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
-    best.G = better ? cand : best.G;
+    best.G2 = med3_i32(best.G, best.G2, cand);
+    best.G = min(cand, best.G);
     best.W = better ? Wp : best.W;
     stk.G = v.stack ? Gp : stk.G;
     stk.W = v.stack ? Wp : stk.W;
@@ -137,7 +135,7 @@ __device__ __forceinline__ void visit_finish(const Visit &v, int t, int Gp, int 
 // holds no computed slot (later slots are empty and would fail the geometry test anyway).
 template <int NS, int PC = 0>
 __device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, int far_upto, const char *T,
-                                              const ICell &c, IBest &best, IBest &stk, ScanMasks &m)
+                                              const ICell &c, RBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC * kC < NS) {
         if (PC * kC < upto) {   // wave-uniform
@@ -222,16 +220,18 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         ic.yTS = sh.g[c.yTS];
         ic.yMM = sh.g[c.yMM];
         // ---- all earlier slots as predecessors
-        IBest best, stk;
+        RBest best;
+        IBest stk;
         best.G = IntTables::kValid;
+        best.G2 = 0x7fffffff;
         best.W = 0;
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
         const int far_upto = wave_min_64(slot < n_cells ? row_lo2 : 63);
         scan_fill_int<NS>(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, ic, best, stk, sm);
-        const bool tie = (sm.tie >> (threadIdx.x & 63)) & 1ull;
-        const bool stHave = (sm.stHave >> (threadIdx.x & 63)) & 1ull;
+        const bool tie = best.G2 == best.G;   // two loop candidates share the minimum
+        const bool stHave = lane_bit(sm.stHave);
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
         //      sides, so T1 > T0 <=> A1 B0 > A0 B1; 620300 B = (2000 H - G) + cq (exact integers
         //      plus one constant: decisive unless the two sides agree to 1e-9).

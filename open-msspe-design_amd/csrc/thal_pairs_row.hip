@@ -39,12 +39,28 @@
 // those of thal_pairs_int.hip; a pair this kernel does not answer goes to the same hand-over list.
 #include "int_core.hpp"
 
+// MSSPE_KO: knock-out switches for timing experiments (tools/variant_build.sh); results are WRONG when set.
+//   1: no tie masks   2: no cell-side select   4: no work after the scan   8: no scan
+#ifndef MSSPE_KO
+#define MSSPE_KO 0
+#endif
+#ifndef MSSPE_ROW_SATSUB
+#define MSSPE_ROW_SATSUB 0
+#endif
+#ifndef MSSPE_ROW_PIPELINE
+#define MSSPE_ROW_PIPELINE 0
+#endif
+#ifndef MSSPE_ROW_THREADS
+#define MSSPE_ROW_THREADS 768
+#define MSSPE_ROW_SLOTS 52
+#endif
+
 namespace msspe {
 
 namespace {
 
 constexpr int kRowK = 13;                        // longest oligo of this kernel
-constexpr int kRowThreads = 768, kRowSlots = 52;
+constexpr int kRowThreads = MSSPE_ROW_THREADS, kRowSlots = MSSPE_ROW_SLOTS;
 constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. 11
 constexpr int kRowA = 772;                       // stride of l2: 4 * 14 * 13 = 728 entries used, = 4 (mod 64)
 constexpr int kRowTEntries = kRowL2 * kRowA;
@@ -65,8 +81,10 @@ struct SharedRow {
     int pick[3][kRowThreads];           // terminal pick: value, word, number of later cells with the same value
     unsigned soft[2][kRowThreads];      // slots whose value has an equal-valued alternative (bit mask)
     int yts[64];                        // [i][m2]: cell-side mismatch term of an interior loop, G units
+    int ytsh[64];                       // ... and its enthalpy / 10
     int g[FastTables::kCount];
-    Lds F;                              // f64 S + int H (replay, end terms)
+    int h[FastTables::kCount];          // enthalpy / 10 per compact-table entry (every finite one is a multiple of 10 cal/mol)
+    short TH[kRowTEntries + 4];         // enthalpy / 10 of the loop term T holds, << 1 | "the lane adds ytsh" (same index)
     double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
     unsigned char pred[kRowSlots][kRowThreads];
     unsigned short path[kPathMax][kRowThreads];
@@ -107,81 +125,98 @@ __device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
 }
 __device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
 
-// The lane's bit of a wave-uniform 64-bit mask (a ballot result): the mask IS a lane predicate, so one
-// v_cndmask reads it; shifting it by the lane number costs a 64-bit shift and a live register pair.
-__device__ __forceinline__ bool lane_bit(unsigned long long m)
-{
-    int r;
-    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
-    return r != 0;
-}
-
 struct RCell {
     unsigned C;     // per-cell minuend of the address subtraction
     int yTS;        // cell-side mismatch term of an interior loop with l2 >= 2
     int idxStk;     // table address that the cell (i-1, j-1) produces
 };
 
+// Table address (byte offset) of predecessor word W seen from the cell with minuend C; a predecessor that
+// is not up-left of the cell lands on a "not available" entry.
+__device__ __forceinline__ unsigned row_index(unsigned C, unsigned W)
+{
+#if MSSPE_ROW_SATSUB
+    return __builtin_elementwise_sub_sat(C, W) >> 15;   // C < W <=> the column difference is negative: entry 0
+#else
+    return min((C - W) >> 15, (unsigned)kRowTBytes);
+#endif
+}
+
+// The table addresses and the (still outstanding) table values of one chunk of slots.
+struct ChunkLoad {
+    unsigned idx[kC];
+    int t[kC];
+};
+
+template <int NS, int PC>
+__device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, const RCell &c, ChunkLoad &L)
+{
+#pragma unroll
+    for (int e = 0; e < kC; ++e)
+        L.idx[e] = row_index(c.C, (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e));
+#pragma unroll
+    for (int e = 0; e < kC; ++e) L.t[e] = *(const int *)(T + L.idx[e]);
+}
+
+// All slots below `upto` as predecessors of the cell, kC at a time; chunks at or above near_from (the
+// row above the cell) also catch the cell (i-1, j-1).  The chunks are unrolled with compile-time register
+// numbers and left through a wave-uniform branch.  Software pipeline: the gathers of chunk PC + 1 are
+// issued before chunk PC is consumed, so that a wave does not park behind every group of gathers (with
+// three waves per SIMD and a third of all instructions scalar, waiting, not issue, was the limit).
 template <int NS, int PC = 0>
-__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int far_upto, const char *T,
-                                              const RCell &c, IBest &best, IBest &stk, ScanMasks &m)
+__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int near_from, const char *T,
+                                              const RCell &c, RBest &best, IBest &stk, ScanMasks &m,
+                                              const ChunkLoad &cur)
 {
     if constexpr (PC * kC < NS) {
         if (PC * kC < upto) {   // wave-uniform
-            unsigned idx[kC];
-            int t[kC];
-            if (PC * kC + kC <= far_upto) {   // wave-uniform: every lane has these slots >= 3 rows up
+            ChunkLoad nxt;
+#if MSSPE_ROW_PIPELINE
+            if constexpr ((PC + 1) * kC < NS) {
+                if ((PC + 1) * kC < upto) chunk_issue<NS, PC + 1>(MSSPE_TAB_ARGS, T, c, nxt);   // wave-uniform
+            }
+#else
+            chunk_issue<NS, PC>(MSSPE_TAB_ARGS, T, c, const_cast<ChunkLoad &>(cur));
+#endif
+            if (PC * kC + kC <= near_from) {   // wave-uniform: slots of rows i-2 and above
                 asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
-#pragma unroll
-                for (int e = 0; e < kC; ++e)
-                    idx[e] = min((c.C - (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e)) >> 15, (unsigned)kRowTBytes);
-#pragma unroll
-                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + idx[e]);
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = t[e] >= kNoY / 2 ? -kNoY : c.yTS;
-                    const int cand = t[e] + y + Gp;   // unavailable: kBig + ..., never below best.G <= kValid
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 ? -kNoY : c.yTS);
+                    const int cand = cur.t[e] + y + Gp;   // unavailable: kBig + ..., never below best.G <= kValid
                     const bool better = cand < best.G;
-                    const bool eq = cand == best.G;
-                    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
-                    best.G = better ? cand : best.G;
+                    if (!(MSSPE_KO & 1)) best.G2 = med3_i32(best.G, best.G2, cand);   // second smallest so far
+                    best.G = min(cand, best.G);
                     best.W = better ? Wp : best.W;
                 }
             } else {
                 asm volatile("" ::"n"(PC + 64));
 #pragma unroll
-                for (int e = 0; e < kC; ++e)
-                    idx[e] = min((c.C - (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e)) >> 15, (unsigned)kRowTBytes);
-#pragma unroll
-                for (int e = 0; e < kC; ++e) t[e] = *(const int *)(T + idx[e]);
-#pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = t[e] >= kNoY / 2 ? -kNoY : c.yTS;
-                    const int cand = t[e] + y + Gp;
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 ? -kNoY : c.yTS);
+                    const int cand = cur.t[e] + y + Gp;
                     const bool better = cand < best.G;
-                    const bool eq = cand == best.G;
-                    m.tie = (m.tie & ~__builtin_amdgcn_ballot_w64(better)) | __builtin_amdgcn_ballot_w64(eq);
-                    best.G = better ? cand : best.G;
+                    if (!(MSSPE_KO & 1)) best.G2 = med3_i32(best.G, best.G2, cand);
+                    best.G = min(cand, best.G);
                     best.W = better ? Wp : best.W;
-                    const bool isstk = idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
+                    const bool isstk = cur.idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
                     stk.G = isstk ? Gp : stk.G;
                     stk.W = isstk ? Wp : stk.W;
                     m.stHave |= __builtin_amdgcn_ballot_w64(isstk);
                 }
             }
-            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, far_upto, T, c, best, stk, m);
+            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, near_from, T, c, best, stk, m, nxt);
         }
     }
 }
 
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  n_cells == 0: idle lane.
 template <int NS>
-__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const SeqPair &q,
-                                                  unsigned rowmask, int n_cells, int nmax)
+__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS,
+                                                  const SeqPair &q, bool active, unsigned wmax4, int n_slots)
 {
-    const Lds &F = sh.F;
     v32i Ga = 0, Wa = kEmptyRowW;
     typename TabTypes<NS>::B Gb = 0, Wb = kEmptyRowW;
     typename TabTypes<NS>::C Gc = 0, Wc = kEmptyRowW;
@@ -191,94 +226,103 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     c.rH = 0;
     c.im1p = c.jm1p = 0;
     c.yTS = c.yMM = c.bBase = 0;
-    unsigned Rrem = rowmask, mrem = 0;
-    int im1 = 0, jm1 = 0;
-    // first slot of the lane's current row and of its two previous non-empty rows: every slot
-    // below row_lo2 lies at least three rows above the current cell
-    int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
     sh.pick[0][threadIdx.x] = 0x7fffffff;   // pickG
     sh.pick[1][threadIdx.x] = 0;            // pickW
     sh.pick[2][threadIdx.x] = 0;            // nTie
     sh.soft[0][threadIdx.x] = sh.soft[1][threadIdx.x] = 0u;
 
-    for (int slot_ = 0; slot_ < nmax; ++slot_) {
+    // Rows are walked by the WAVE: every lane shares oligo 1, so row i holds the cells whose oligo-2 base
+    // is 3 - s1[i], and a row takes as many slots as its widest lane has cells there (lanes with fewer
+    // publish an empty slot, which fails every geometry test).  Composition-sorted lanes differ by a
+    // base or two, so the padding is about 1 % of the slots; in exchange the row number, the row's
+    // first slot, the near / far boundary and everything cell_bases() takes from oligo 1 are scalars.
+    int slot_ = 0, start_im1 = 0;   // first slot of row i-1
+    for (int i_ = 0; i_ < q.len; ++i_) {
+      const int im1 = __builtin_amdgcn_readfirstlane(i_);
+      const int a_row = (int)((q.s1 >> (2 * im1)) & 3u);
+      const int w_row = (int)((wmax4 >> (8 * (3 - a_row))) & 0xffu);   // widest lane's cells in this row
+      const int row_start = __builtin_amdgcn_readfirstlane(slot_);
+      unsigned mrem = active ? spaced_mask(q.s2, 3 - a_row, q.lenmask) : 0u;
+      for (int c_ = 0; c_ < w_row; ++c_, ++slot_) {
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
-        // ---- next complementary cell in row-major order
-        const bool newrow = mrem == 0;
-        const int t = __ffs((int)Rrem) - 1;
-        const int a_new = (q.s1 >> (t & 31)) & 3;
-        const unsigned m_new = spaced_mask(q.s2, 3 - a_new, q.lenmask);
-        im1 = newrow ? (t >> 1) : im1;
-        row_lo2 = newrow ? row_lo1 : row_lo2;
-        row_lo1 = newrow ? row_lo0 : row_lo1;
-        row_lo0 = newrow ? slot : row_lo0;
-        Rrem = newrow ? (Rrem & (Rrem - 1)) : Rrem;
-        mrem = newrow ? m_new : mrem;
-        jm1 = (__ffs((int)mrem) - 1) >> 1;
+        // ---- the lane's next complementary cell of this row (none: an empty slot)
+        const bool in = mrem != 0u;
+        const int jm1 = ((__ffs((int)mrem) - 1) >> 1) & 15;
         mrem &= mrem - 1;
-        im1 &= 15;
-        jm1 &= 15;
         RCell rc;
         rc.C = ((unsigned)((jm1 - 1) * kRowA + im1 * 60 + 3) << 17) | 0x7fffu;
         // m2 = base left of the cell on oligo 2 (0 in column 0, where no loop can close)
         rc.yTS = sh.yts[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)];
         rc.idxStk = ((im1 * 14 + 1) * 4 + (int)((q.s1 >> (2 * im1)) & 3u)) * 4;   // l2 = 0, i - ii = 1, 3 - n2 = base of the cell
         // ---- all earlier slots as predecessors
-        IBest best, stk;
+        RBest best;
+        IBest stk;
         best.G = IntTables::kValid;
+        best.G2 = 0x7fffffff;
         best.W = 0;
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
-        const int far_upto = wave_min_64(slot < n_cells ? row_lo2 : 63);
-        scan_fill_row<NS>(MSSPE_TAB_ARGS, slot, far_upto, (const char *)sh.T, rc, best, stk, sm);
-        const bool tie = lane_bit(sm.tie);
+        // predecessors: every slot of the rows above; row i-1 (where the cell (i-1, j-1) lives) through
+        // the code that catches it
+        ChunkLoad first;
+#if MSSPE_ROW_PIPELINE
+        if (row_start > 0) chunk_issue<NS, 0>(MSSPE_TAB_ARGS, (const char *)sh.T, rc, first);   // wave-uniform
+#endif
+        if (!(MSSPE_KO & 8)) scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, best, stk, sm, first);
+        const bool tie = best.G2 == best.G;   // two loop candidates share the minimum
         const bool stHave = lane_bit(sm.stHave);
         const CellBases b = cell_bases(q, im1, jm1, c);   // after the scan: nothing of it is live across it
-        // ---- thal.c maxTM(): helix extension if it raises Tm (see thal_pairs_int.hip)
-        int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
-        if (stHave) {
-            const int rH = F.H[b.idxR];
-            const double cq = sh.cq[b.idxR - FastTables::kEndR];
-            const int H1 = word_h(stk.W) * 10 + F.H[b.wc];
-            const int G1 = stk.G + sh.g[b.wc];
-            const double A0 = (double)(H0 + 200 + rH), A1 = (double)(H1 + 200 + rH);
-            const double B0 = (double)(2000 * H0 - G0) + cq, B1 = (double)(2000 * H1 - G1) + cq;
+        // ---- thal.c maxTM(): helix extension if it raises Tm (see thal_pairs_int.hip).  Enthalpies in units
+        //      of 10 cal/mol (h): T = A / B with A = 10 (h + 20 + rh), 620300 B = 20000 h - G + cq; the
+        //      factor 10 drops out of A1 B0 > A0 B1
+        // (every LDS read of the cell's own terms is issued here, in one group: one wait, not four)
+        int h0 = sh.h[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
+        const int rh = sh.h[b.idxR], gR = sh.g[b.idxR], hwc = sh.h[b.wc], gwc = sh.g[b.wc];
+        const double cq = sh.cq[b.idxR - FastTables::kEndR];
+        const int pickG = sh.pick[0][threadIdx.x];
+        if (stHave && !(MSSPE_KO & 4)) {
+            const int h1 = word_h(stk.W) + hwc;
+            const int G1 = stk.G + gwc;
+            const double A0 = (double)(h0 + 20 + rh), A1 = (double)(h1 + 20 + rh);
+            const double B0 = (double)(20000 * h0 - G0) + cq, B1 = (double)(20000 * h1 - G1) + cq;
             const double lhs = A1 * B0, rhs = A0 * B1;
             const bool sure = (B0 < 0.0) & (B1 < 0.0) & (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
             flags |= sure ? 0 : kDeferTm;
             if (lhs > rhs) {
-                H0 = H1;
+                h0 = h1;
                 G0 = G1;
                 pred = word_cw(stk.W);
             }
         }
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
-        if (best.G <= G0) {
-            // exact enthalpy of the best candidate from the compact tables
-            const CandGeom g = cand_geometry(c, core_word_row(best.W, q.s1));
-            const int Hw = F.H[g.lx] + F.H[g.y] + word_h(best.W) * 10;
+        if (best.G <= G0 && !(MSSPE_KO & 4)) {
+            // exact enthalpy of the best candidate: the loop term's from the table that mirrors T
+            const unsigned idx = row_index(rc.C, (unsigned)best.W);
+            const int th = sh.TH[idx >> 2];
+            const int hw = (th >> 1) + ((th & 1) ? sh.ytsh[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)] : 0) +
+                           word_h(best.W);
             if (best.G < G0) {
                 flags |= tie ? kDeferLoopTie : 0;
-                flags |= ((Hw > 0) & (2000 * Hw - best.G > -1000)) ? kDeferBad : 0;
-                H0 = Hw;
+                // thal.c rejects a candidate with H > 0 and S > 0 (620300 S = 2000 H - G)
+                flags |= ((hw > 0) & (20000 * hw - best.G > -1000)) ? kDeferBad : 0;
+                h0 = hw;
                 G0 = best.G;
                 pred = word_cw(best.W);
-            } else if (Hw == H0) {
-                if (slot < n_cells) sh.soft[slot >> 5][threadIdx.x] |= 1u << (slot & 31);
+            } else if (hw == h0) {
+                if (in) sh.soft[slot >> 5][threadIdx.x] |= 1u << (slot & 31);
             } else {
                 flags |= kDeferLoopEq;
             }
         }
-        const int hb = H0 / 10 + kHBias;
+        const int hb = h0 + kHBias;
         flags |= ((unsigned)hb > 0x7fffu) ? kDeferReplay : 0;   // enthalpy beyond the 15-bit field: hand the pair on
-        const int Wcell = (int)((unsigned)(jm1 * kRowA + (im1 << 2) + ((b.po_c >> 4) & 3)) << 17) | (hb & 0x7fff);
-        const bool in = slot < n_cells;   // lanes past their last cell compute garbage
+        const int Wcell = in ? ((int)((unsigned)(jm1 * kRowA + (im1 << 2) + ((b.po_c >> 4) & 3)) << 17) | (hb & 0x7fff))
+                             : kEmptyRowW;   // lanes without a cell here compute garbage and publish an empty slot
         defer |= in ? flags : 0;
         // ---- terminal pick (strict minimum of dG incl. the right end term, first in slot order)
         {
-            const int Gt = G0 + sh.g[b.idxR];
-            const int pickG = sh.pick[0][threadIdx.x];
+            const int Gt = G0 + gR;
             if (in & (Gt < pickG)) {
                 sh.pick[0][threadIdx.x] = Gt;
                 sh.pick[1][threadIdx.x] = Wcell;
@@ -291,28 +335,36 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0;
             Wa[slot & 31] = Wcell;
-        } else if constexpr (NS == 52) {
+        } else if constexpr (NS == 64) {
+            Gb[(slot - 32) & 31] = G0;
+            Wb[(slot - 32) & 31] = Wcell;
+        } else if constexpr (NS == 48) {
+            Gb[(slot - 32) & 15] = G0;
+            Wb[(slot - 32) & 15] = Wcell;
+        } else {
             if (slot < 48) {
                 Gb[(slot - 32) & 15] = G0;
                 Wb[(slot - 32) & 15] = Wcell;
-            } else {
+            } else if constexpr (NS == 52) {
                 Gc[(slot - 48) & 3] = G0;
                 Wc[(slot - 48) & 3] = Wcell;
+            } else {
+                Gc[(slot - 48) & 7] = G0;
+                Wc[(slot - 48) & 7] = Wcell;
             }
-        } else {
-            Gb[(slot - 32) & 15] = G0;
-            Wb[(slot - 32) & 15] = Wcell;
         }
         sh.pred[slot][threadIdx.x] = (unsigned char)pred;
+      }
+      start_im1 = row_start;
     }
 
     IntResult out;
-    out.r.none = n_cells == 0;
+    out.r.none = !active;
     out.r.dG = INFINITY;
     out.r.t = 0.0;
     out.r.conflict = false;
 
-    const int nch = (nmax + kC - 1) / kC;
+    const int nch = (n_slots + kC - 1) / kC;
     defer |= sh.pick[2][threadIdx.x] > 0 ? kDeferPick : 0;   // a second walk would be paid by the whole wave: handed on
     const unsigned long long softTie =
         (unsigned long long)sh.soft[0][threadIdx.x] | ((unsigned long long)sh.soft[1][threadIdx.x] << 32);
@@ -334,7 +386,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
             for (int e = kC - 1; e >= 0; --e) {
                 const int slot = pc * kC + e;
                 const int pr = sh.pred[slot][threadIdx.x];
-                const bool hit = !done & (slot < n_cells) & (word_sig(W[e]) == cur);
+                const bool hit = !done & (word_sig(W[e]) == cur);   // an empty slot matches no cell
                 if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)((unsigned)W[e] >> 17);
                 dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
                 P += hit ? 1 : 0;
@@ -354,32 +406,31 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 CellCtx cc;
                 const CellBases b = cell_bases(q, (core >> 4) & 15, core & 15, cc);
                 if (step == 0) {
-                    S = F.S[b.idxL];
-                    H = F.H[b.idxL];
+                    S = gS[b.idxL];
+                    H = sh.h[b.idxL];
                 } else if (((core & 0xff) - (prevCore & 0xff)) == 0x11) {   // the cell (i-1, j-1): stacked pair
-                    S = S + F.S[b.wc];
-                    H = H + F.H[b.wc];
+                    S = S + gS[b.wc];
+                    H = H + sh.h[b.wc];
                 } else {
                     const CandGeom g = cand_geometry(cc, prevCore);
-                    const CandLoad v = cand_gather(F, g);
-                    S = ((v.sLX + v.sY) + v.sZ) + S;
-                    H = v.hLX + v.hY + H;
+                    S = ((gS[g.lx] + gS[g.y]) + gS[g.zi]) + S;   // thal.c's order (pair_core.hpp cand_finish)
+                    H = sh.h[g.lx] + sh.h[g.y] + H;
                 }
                 prevCore = core;
             }
         }
     }
     // the replayed enthalpy must be the tracked one; anything else is handed on
-    dpath |= (!out.r.none & (H != word_h(endW) * 10)) ? kDeferReplay : 0;
+    dpath |= (!out.r.none & (H != word_h(endW))) ? kDeferReplay : 0;   // H in units of 10 cal/mol here
     defer |= dpath;
     // ---- thal.c drawDimer(): totals
     {
         const KParts pe = k_parts((unsigned)endW >> 17);
         CellCtx cc;
         const CellBases b = cell_bases(q, pe.ii, pe.jj, cc);
-        const double rS = F.S[b.idxR];
-        const int rH = F.H[b.idxR];
-        const double dH = (double)(H + rH + 200);
+        const double rS = gS[b.idxR];
+        const int rH = sh.h[b.idxR];
+        const double dH = (double)((H + rH) * 10 + 200);
         const double dS = (S + rS) + K.init_S;
         const int N = P - 1;
         const double t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
@@ -421,6 +472,37 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
         }
         nmax = next;
     }
+    // Slots the wave needs: row i takes the widest lane's count of base 3 - s1[i].  If that is more than
+    // the table holds, the lanes with the most cells leave for the list stage until it fits.
+    const unsigned lenmask = q.lenmask;
+    int c2[4], w4[4] = {0, 0, 0, 0}, n_slots = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c2[b] = __popc(spaced_mask(q.s2, b, lenmask));
+    for (;;) {
+        if (nmax == 0) break;   // wave-uniform
+        n_slots = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            w4[b] = wave_max(n_cells > 0 ? c2[b] : 0);
+            n_slots += w4[b] * __popc(spaced_mask(q.s1, 3 - b, lenmask));   // rows whose cells have base b on oligo 2
+        }
+        if (n_slots <= NS) break;
+        // Too many slots: the wave mixes compositions (it straddles a bin boundary, or the pool is small).
+        // Keep the larger party: lanes with the composition of the first active lane stay if they are at
+        // least half of the active lanes, else they are the ones to go.  (Lanes of one composition need
+        // exactly their own cell count, which fits: larger tables left above.)
+        const unsigned sig = (unsigned)c2[0] | ((unsigned)c2[1] << 8) | ((unsigned)c2[2] << 16) | ((unsigned)c2[3] << 24);
+        const unsigned long long act = __ballot(n_cells > 0);
+        const unsigned sig0 = (unsigned)__shfl((int)sig, __ffsll((long long)act) - 1);
+        const unsigned long long same = __ballot(n_cells > 0 && sig == sig0);
+        const bool keep_same = 2 * __popcll(same) >= __popcll(act);
+        const bool uniform = same == act;   // cannot happen with n_slots > NS; never loop on it
+        if (n_cells > 0 && (uniform ? n_cells == nmax : ((sig == sig0) != keep_same))) {
+            spill = true;
+            n_cells = 0;
+        }
+        nmax = wave_max(n_cells);
+    }
     if (nmax == 0) {   // wave-uniform: nothing to compute
         if (spill) {
             const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
@@ -428,7 +510,8 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
         }
         return;
     }
-    const IntResult r = run_pair_row<NS>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, n_cells > 0, wmax4, n_slots);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;
@@ -483,37 +566,50 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
 __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a, unsigned s1)
 {
     const int32_t *Tg = a.it->T;
+    const int32_t *Hg = a.f.ft->H;
     for (int e = threadIdx.x; e < kRowTEntries; e += kRowThreads) {
         const int l2 = e / kRowA, rem = e - l2 * kRowA;
         const int n2 = 3 - (rem & 3), ir = rem >> 2, i = ir / 14, r = ir - i * 14;
         const int ii = i - r, l1 = r - 1;
-        int v = IntTables::kBig;
+        int v = IntTables::kBig, hv = 0;
         bool needs_y = false;
         if (r >= 1 && ii >= 0 && i < a.f.k && (l1 | l2) != 0 && l1 <= IntTables::kMaxL) {
             const int d = l1 * 16 + l2;
             const int a_p = (int)((s1 >> (2 * ii)) & 3u), a_c = (int)((s1 >> (2 * i)) & 3u);
+            const int sz = l1 + l2;
             if (l1 == 0 || l2 == 0) {
                 v = Tg[d * 64 + (a_p | (a_c << 2))];
+                hv = Hg[FastTables::kBU + a_c * FastTables::kBUStride + sz * 4 + a_p];
             } else {
                 const int n1 = (int)((s1 >> (2 * ii + 2)) & 3u);
-                v = Tg[d * 64 + (a_p | (n1 << 2) | (n2 << 4))];
+                const int po = a_p | (n1 << 2) | (n2 << 4);
+                v = Tg[d * 64 + po];
+                hv = Hg[FastTables::kNB + (sz - 2) * 64 + po];
                 if (l2 == 1) {
                     const int m1 = (int)((s1 >> (2 * i - 2)) & 3u);
                     const int ci = ((3 - a_c) * 4 + n2) * 4 + m1;
-                    const int y = sh.g[(d == 0x11 ? FastTables::kMMc : FastTables::kTSc) + ci];
+                    const int ye = (d == 0x11 ? FastTables::kMMc : FastTables::kTSc) + ci;
+                    const int y = sh.g[ye];
                     v = (v >= IntTables::kValid || y >= IntTables::kValid) ? IntTables::kBig : v + y;
+                    hv += sh.h[ye] * 10;
                 } else {
                     needs_y = v < IntTables::kValid;
                 }
             }
+            if (v >= IntTables::kValid) hv = 0;
         }
         sh.T[e] = needs_y ? v : v + kNoY;
+        sh.TH[e] = (short)(((hv / 10) << 1) | (needs_y ? 1 : 0));
     }
-    if (threadIdx.x < 4) sh.T[kRowTEntries + threadIdx.x] = IntTables::kBig + kNoY;
+    if (threadIdx.x < 4) {
+        sh.T[kRowTEntries + threadIdx.x] = IntTables::kBig + kNoY;
+        sh.TH[kRowTEntries + threadIdx.x] = 0;
+    }
     if (threadIdx.x < 64) {
         const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
         const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
         sh.yts[threadIdx.x] = sh.g[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+        sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
     }
 }
 
@@ -522,8 +618,7 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
 {
     __shared__ SharedRow sh;
     for (int e = threadIdx.x; e < FastTables::kCount; e += kRowThreads) {
-        sh.F.S[e] = a.f.ft->S[e];
-        sh.F.H[e] = a.f.ft->H[e];
+        sh.h[e] = a.f.ft->H[e] / 10;   // finite entries are multiples of 10 (build_int_tables); "not available" stays huge
         sh.g[e] = a.it->g[e];
     }
     for (int e = threadIdx.x; e < 100; e += kRowThreads)

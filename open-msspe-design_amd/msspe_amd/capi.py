@@ -55,6 +55,16 @@ def lib_path() -> Path:
     return PKG_DIR / "libmsspe_hip.so"
 
 
+_lib_override: Path | None = None
+
+
+def use_library(path) -> None:
+    """Development aid (tools/variant_build.sh): load another build of the library; call before the
+    first Engine is created."""
+    global _lib_override
+    _lib_override = Path(path)
+
+
 _lib = None
 
 
@@ -66,7 +76,7 @@ def load_library() -> C.CDLL:
         import torch          # process it must be loaded first so that a single runtime exists
     except Exception:         # (torch is plumbing here: device buffers, streams, torch.distributed)
         pass
-    p = lib_path()
+    p = _lib_override or lib_path()
     if not p.exists():
         raise ImportError(f"{p} is missing: build it with open-msspe-design_amd/build.sh "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")

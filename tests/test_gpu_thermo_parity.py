@@ -277,9 +277,9 @@ def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypat
     for key in ("dg", "tm", "bitmap", "row_conflicts"):
         np.testing.assert_array_equal(a[key], b[key])
         np.testing.assert_array_equal(a[key], c[key])
-    # the row-specialised kernel and the general one hand on the same pairs for the same reasons
-    flat = lambda d: {k: v for k, v in d.items() if k not in ("list", "needed_f64")}
-    assert flat(stats) == flat(stats_general)
+    # (how many pairs each first stage answers itself differs: the row kernel pads a wave's rows to its
+    # widest lane, and in a pool this small every wave mixes compositions; both see ties)
+    assert stats_general["deferred"] > 0 and stats_general["replay_mismatch"] == 0
     n2 = len(pool) ** 2
     assert 0 < stats["deferred"] < 0.06 * n2                  # retried in list mode
     assert 0 < stats["needed_f64"] < 0.01 * n2                # what only the f64 kernels can answer

@@ -15,6 +15,9 @@ def main():
     import os
     sizes = [int(x) for x in sys.argv[1:]] or [2048, 8192]
     K = int(os.environ.get("MSSPE_PROBE_K", "13"))
+    if os.environ.get("MSSPE_PROBE_LIB"):
+        from msspe_amd import capi
+        capi.use_library(os.environ["MSSPE_PROBE_LIB"])
     eng = m.Engine(0)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     chem = m.Chem.ntthal()
