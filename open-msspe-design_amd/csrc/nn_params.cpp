@@ -429,10 +429,16 @@ static double from_key(uint64_t k)
 
 double g_cut(float threshold)
 {
-    // decision(x) = round_g_f32(x) < threshold is monotone (true for small x).  Return the
-    // largest double for which it is true, so that the kernels can test dG <= cut.
+    // The reference keeps an edge when the %g text of dG, parsed as f32, is below the threshold
+    // (delta_g.rs:33-36), stores it as "{:.2}" (:45) and tests the re-parsed text again (main.rs:758,
+    // delta_g.rs:10-15): below |dG| = 1000 the second text is coarser than the first and can lift a value
+    // back to the threshold.  Both roundings are monotone, so the conjunction is (true for small x):
+    // return the largest double for which it is true, so that the kernels can test dG <= cut.
     if (std::isnan(threshold)) return -INFINITY;
-    auto dec = [&](double x) { return round_g_f32(x) < threshold; };
+    auto dec = [&](double x) {
+        const float first = round_g_f32(x);
+        return first < threshold && round_fixed_f32((double)first, 2) < threshold;
+    };
     uint64_t lo = ordered_key(-DBL_MAX), hi = ordered_key(DBL_MAX);
     if (!dec(from_key(lo))) return -INFINITY;
     if (dec(from_key(hi))) return DBL_MAX;

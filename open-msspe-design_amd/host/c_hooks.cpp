@@ -86,6 +86,16 @@ int odm_vertex_cover(const char *primers_nl, const char *edges_nl, char *out, si
 
 int odm_is_run(const char *kmer) { return is_run(kmer) ? 1 : 0; }
 
+// primers: one per line -> the text the reference would pipe into ntthal (delta_g.rs:61-81)
+int odm_format_ntthal_input(const char *primers_nl, int check_cross_dimers, int check_self_dimers, char *out,
+                            size_t cap)
+{
+    ProgramConfig cfg{};
+    cfg.check_cross_dimers = check_cross_dimers != 0;
+    cfg.check_self_dimers = check_self_dimers != 0;
+    return emit(format_ntthal_input(lines(primers_nl), cfg), out, cap);
+}
+
 // FASTA text -> "name\tsequence" lines
 int odm_to_records(const char *fasta, char *out, size_t cap)
 {

@@ -16,10 +16,14 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <spawn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <unordered_set>
+
+extern char **environ;
 
 namespace od_msspe {
 
@@ -435,6 +439,26 @@ std::vector<KmerStat> filter_kmers(const std::vector<KmerStat> &stats, const Pro
 // ---------------------------------------------------------------------------------------------
 // stage C (delta_g.rs:61-153) and the vertex cover (main.rs:754-798)
 // ---------------------------------------------------------------------------------------------
+// delta_g.rs:64-73: is the ordered pair (a, b) sent to ntthal at all?
+bool ntthal_pair_sent(const std::string &a, const std::string &b, const ProgramConfig &cfg)
+{
+    if (!cfg.check_self_dimers && (a == b || reverse_complement(b) == a)) return false;
+    return cfg.check_cross_dimers;
+}
+
+// delta_g.rs:61-81: every ordered pair that is sent, "a,b" per line, no trailing newline.  The engine
+// takes the packed pool instead of this text; the function exists as the statement of WHICH pairs count
+// (run_ntthal below applies the same predicate to the bitmap) and for the ntthal-compatible shim's tests.
+std::string format_ntthal_input(const std::vector<std::string> &primers, const ProgramConfig &cfg)
+{
+    std::string out;
+    for (const auto &a : primers)
+        for (const auto &b : primers)
+            if (ntthal_pair_sent(a, b, cfg)) out += a + "," + b + "\n";
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();   // .trim()
+    return out;
+}
+
 ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
                          const NtthalOptions &opts, const ProgramConfig &cfg)
 {
@@ -462,10 +486,7 @@ ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
         for (int b = 0; b < n; ++b) {
             if (!((bitmap[(size_t)a * words + (size_t)(b >> 6)] >> (b & 63)) & 1ull)) continue;
             // delta_g.rs:66-69: pairs never sent to ntthal when self-dimer checking is off
-            if (!cfg.check_self_dimers &&
-                (g.nodes[(size_t)a] == g.nodes[(size_t)b] ||
-                 reverse_complement(g.nodes[(size_t)b]) == g.nodes[(size_t)a]))
-                continue;
+            if (!ntthal_pair_sent(g.nodes[(size_t)a], g.nodes[(size_t)b], cfg)) continue;
             g.edges[g.nodes[(size_t)a]].insert(g.nodes[(size_t)b]);
         }
     return g;
@@ -639,14 +660,55 @@ struct PhaseTimer {
 };
 }  // namespace
 
+// main.rs:127-146 align_sequences(): `mafft --auto --quiet --thread -1 --op 1.53 --ep 0.123 --jtt 200 <file>`
+// as a child process, its stdout is the aligned FASTA.  Like the reference (Command::output()) the exit
+// status is not looked at and stderr is discarded; a mafft that cannot be started panics with
+// std::process's message.  Runs before the engine is created: no process that holds a GPU spawns anything.
+std::string align_sequences(const std::string &filepath)
+{
+    int fds[2];
+    if (::pipe(fds) != 0) throw Panic("failed to execute MAFFT: cannot create a pipe");
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, fds[1], STDOUT_FILENO);
+    posix_spawn_file_actions_addopen(&fa, STDERR_FILENO, "/dev/null", O_WRONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, STDIN_FILENO, "/dev/null", O_RDONLY, 0);
+    posix_spawn_file_actions_addclose(&fa, fds[0]);
+    posix_spawn_file_actions_addclose(&fa, fds[1]);
+    const char *argv[] = {"mafft", "--auto", "--quiet", "--thread", "-1", "--op", "1.53", "--ep", "0.123",
+                          "--jtt", "200", filepath.c_str(), nullptr};
+    pid_t pid = 0;
+    const int rc = ::posix_spawnp(&pid, "mafft", &fa, nullptr, const_cast<char *const *>(argv), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    ::close(fds[1]);
+    if (rc != 0) {
+        ::close(fds[0]);
+        throw Panic(std::string("failed to execute MAFFT: Os { code: ") + std::to_string(rc) + ", kind: " +
+                    (rc == ENOENT ? "NotFound" : "Other") + ", message: \"" + std::strerror(rc) + "\" }");
+    }
+    std::string out;
+    char buf[1 << 16];
+    for (;;) {
+        const ssize_t got = ::read(fds[0], buf, sizeof buf);
+        if (got > 0) out.append(buf, (size_t)got);
+        else if (got == 0 || errno != EINTR) break;
+    }
+    ::close(fds[0]);
+    int status = 0;
+    while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    }
+    return out;
+}
+
 int run(const Args &args, std::string &stdout_text)
 {
     PhaseTimer timer;
-    if (args.do_align == "true")
-        throw std::runtime_error("--do-align true: MAFFT is a host-side pre-step outside this engine; "
-                                 "align the input first and pass --do-align false");
     std::vector<SequenceRecord> records;
-    {
+    if (args.do_align == "true") {   // the reference's default (config.rs:131-138)
+        const std::string aligned = align_sequences(args.input);
+        records = to_records(aligned);
+        timer.lap("mafft");
+    } else {
         // regular files are mapped and parsed in place (no copy of a multi-hundred-MB input);
         // anything else (pipes) is read through a stream
         const int fd = ::open(args.input.c_str(), O_RDONLY);

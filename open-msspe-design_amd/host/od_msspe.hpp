@@ -76,6 +76,8 @@ struct SequenceRecord {   // main.rs:21-24
 std::vector<SequenceRecord> to_records(const std::string &fasta);   // main.rs:108-122
 std::vector<SequenceRecord> to_records(const char *fasta, size_t size);
 std::string reverse_complement(const std::string &s);               // main.rs:148-161
+bool ntthal_pair_sent(const std::string &a, const std::string &b, const ProgramConfig &cfg);   // delta_g.rs:64-73
+std::string format_ntthal_input(const std::vector<std::string> &primers, const ProgramConfig &cfg);   // delta_g.rs:61-81
 
 struct KmerFrequency {   // main.rs:47-51
     std::string word;

@@ -13,7 +13,7 @@ STATUS = {0: "MSSPE_OK", 1: "MSSPE_ERR_ARG", 2: "MSSPE_ERR_K", 3: "MSSPE_ERR_TAB
 # every symbol include/msspe_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "msspe_chem_ntthal_defaults", "msspe_chem_primer3_defaults", "msspe_create", "msspe_destroy",
-    "msspe_last_error", "msspe_version", "msspe_set_stream", "msspe_reset_stream",
+    "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
     "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_host_split_tables", "msspe_device_put_rows", "msspe_segment_coverage", "msspe_segment_coverage_dev",

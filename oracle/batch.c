@@ -18,7 +18,7 @@ int orc_thal_dimer(const orc_tables *t, const char *oligo1, const char *oligo2, 
 /*
  * pool: n oligos of k chars each, concatenated (no NULs).  Rows [row0,row1) x all n columns.
  * dg_out       (optional) (row1-row0)*n doubles, +inf where thal finds no structure
- * conflict_out (optional) (row1-row0)*n bytes, 1 where round_g(dG) as f32 < threshold
+ * conflict_out (optional) (row1-row0)*n bytes, 1 where the reference keeps the edge (orc_edge_decision)
  * returns the number of conflicts, or -1.
  */
 long orc_pool_pairs(const orc_tables *t, const char *pool, int n, int k, int row0, int row1,
@@ -48,7 +48,7 @@ long orc_pool_pairs(const orc_tables *t, const char *pool, int n, int k, int row
             orc_thal_dimer(t, a, b, mode, args, &r);
             const size_t o = (size_t)(i - row0) * (size_t)n + (size_t)j;
             int c = 0;
-            if (!r.no_structure) c = orc_round_g_f32(r.dG) < threshold;
+            if (!r.no_structure) c = orc_edge_decision(r.dG, threshold);
             if (dg_out) dg_out[o] = r.no_structure ? INFINITY : r.dG;
             if (t_out) t_out[o] = r.no_structure ? 0.0 : r.t;
             if (conflict_out) conflict_out[o] = (unsigned char)c;

@@ -125,6 +125,7 @@ int orc_check_primer(const orc_tables *t, const char *oligo, orc_primer_info *ou
 /* ------------------------------------------------------------------------------------------
  * Text rounding at the process boundary
  * ---------------------------------------------------------------------------------------- */
+int orc_edge_decision(double dG, float threshold);   /* both filters of the reference: delta_g.rs:33-36 and main.rs:758 */
 float orc_round_g_f32(double x);       /* printf("%g") -> parse::<f32>()  (delta_g.rs:33-36) */
 float orc_round_fixed_f32(double x, int decimals);   /* "%.3f"/"%.2f" -> f32 (primer.rs:94-106) */
 /* ntthal-pipeline decision for one ordered pair: 1 = conflict edge (dG < threshold). */

@@ -143,6 +143,17 @@ double orc_gc_percent(const char *oligo)
     return n ? 100.0 * ((double)gc) / n : 0.0;
 }
 
+/* The reference filters an edge twice: parse_ntthal_output keeps it when the %g text of dG, parsed as
+ * f32, is below the threshold (od-msspe/src/delta_g.rs:33-36) and stores it as "{:.2}" (:45); main.rs:758
+ * then re-parses that text (delta_g.rs:10-15) and tests `< threshold` again.  Below |dG| = 1000 the
+ * first text has more than two decimals, so the second test can drop an edge the first one kept. */
+int orc_edge_decision(double dG, float threshold)
+{
+    const float first = orc_round_g_f32(dG);
+    if (!(first < threshold)) return 0;
+    return orc_round_fixed_f32((double)first, 2) < threshold;
+}
+
 float orc_round_g_f32(double x)
 {
     char buf[64];
@@ -189,7 +200,7 @@ int orc_pair_conflict(const orc_tables *t, const char *a, const char *b,
         return 0;
     }
     if (dg_out) *dg_out = r.dG;
-    return orc_round_g_f32(r.dG) < threshold;
+    return orc_edge_decision(r.dG, threshold);
 }
 
 int orc_is_run(const char *kmer)

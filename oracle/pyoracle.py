@@ -239,6 +239,14 @@ def round_fixed_f32(x: float, decimals: int) -> float:
     return float(lib().orc_round_fixed_f32(x, decimals))
 
 
+def edge_decision(dg: float, threshold: float) -> bool:
+    """Both filters of the reference (delta_g.rs:33-36, then main.rs:758 on the "{:.2}" text)."""
+    L = lib()
+    L.orc_edge_decision.restype = C.c_int
+    L.orc_edge_decision.argtypes = [C.c_double, C.c_float]
+    return bool(L.orc_edge_decision(dg, C.c_float(threshold)))
+
+
 def reverse_complement(s: str) -> str:
     out = C.create_string_buffer(len(s) + 1)
     lib().orc_reverse_complement(s.encode(), len(s), out)

@@ -77,3 +77,22 @@ def test_primer3_shim_golden(golden_dir):
     assert (kv["PRIMER_LEFT_0_SELF_ANY_TH"], kv["PRIMER_LEFT_0_SELF_END_TH"], kv["PRIMER_LEFT_0_HAIRPIN_TH"]) == \
         ("0.00", "0.00", "0.00")
     assert res.stdout.rstrip().endswith("=")
+
+
+def test_ntthal_shim_answers_the_reference_input_text_in_order(golden_dir):
+    """The text of delta_g.rs:162-193 (four ordered pairs, no trailing newline) piped into the shim with
+    the reference's argv: one 5-line block per input line, in input order, so that parse_ntthal_output's
+    zip (delta_g.rs:31-56) attributes every dG to the right pair."""
+    import pyoracle
+    g = json.loads((golden_dir / "ntthal_format.json").read_text())
+    stdin = g["expected"]
+    res = subprocess.run([str(BIN / "ntthal-hip"), "-a", "ANY", "-mv", "50.00", "-dv", "3.00", "-n", "0.00",
+                          "-d", "250.00", "-t", "25.00", "-i"], input=stdin, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.splitlines()
+    pairs = [l.split(",") for l in stdin.split("\n")]
+    assert len(lines) == 5 * len(pairs)
+    tables = pyoracle.Tables()
+    for q, (a, b) in enumerate(pairs):
+        want = pyoracle.thal(tables, a, b, pyoracle.ANY, pyoracle.ntthal_args())
+        assert lines[5 * q].split()[13] == "%g" % want.dG

@@ -187,3 +187,74 @@ def test_end_to_end_cli_matches_the_restated_pipeline(host, tmp_path, extra, kw)
     assert csv.read_text() == want_csv
     assert report == want_report
     assert want_csv.count("\n") > 3
+
+
+def _fake_mafft(tmp_path, body):
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    exe = bindir / "mafft"
+    exe.write_text("#!/bin/sh\n" + body)
+    exe.chmod(0o755)
+    return bindir
+
+
+def test_default_invocation_runs_mafft_with_the_reference_argv(host, tmp_path, monkeypatch):
+    """od-msspe/src/main.rs:127-146 + config.rs:131-138: --do-align defaults to "true" and the input goes
+    through `mafft --auto --quiet --thread -1 --op 1.53 --ep 0.123 --jtt 200 <file>`; its stdout is the
+    FASTA.  A fake mafft records its argv and emits nothing, so the run ends in the reference's next
+    panic ("No sequences found"), before any GPU call."""
+    log = tmp_path / "argv.txt"
+    bindir = _fake_mafft(tmp_path, f'printf "%s\\n" "$@" > {log}\n')
+    monkeypatch.setenv("PATH", f"{bindir}:/usr/bin:/bin")
+    fa = tmp_path / "in.fa"
+    fa.write_text(">a\nACGT\n")
+    rc, out = call(host.odm_run_cli, *argv("-i", str(fa), "-o", str(tmp_path / "o.csv")))
+    assert rc == 101 and out == "No sequences found in the input file"
+    assert log.read_text().split("\n")[:-1] == ["--auto", "--quiet", "--thread", "-1", "--op", "1.53", "--ep",
+                                                "0.123", "--jtt", "200", str(fa)]
+
+
+def test_mafft_output_is_the_alignment_that_gets_screened(host, tmp_path, monkeypatch):
+    """The aligned FASTA on mafft's stdout replaces the input file (here: a fake mafft that prints a
+    different file); without a GPU the run then stops at the engine, with one it completes."""
+    import torch
+    aligned = tmp_path / "aligned.fa"
+    aligned.write_text(">x\n" + "ACGT" * 200 + "\n>y\n" + "ACGT" * 200 + "\n")
+    bindir = _fake_mafft(tmp_path, f"cat {aligned}\n")
+    monkeypatch.setenv("PATH", f"{bindir}:/usr/bin:/bin")
+    fa = tmp_path / "in.fa"
+    fa.write_text(">unaligned\nAC\n")
+    rc, out = call(host.odm_run_cli, *argv("-i", str(fa), "-o", str(tmp_path / "o.csv")))
+    if torch.cuda.is_available():
+        assert rc == 0, out
+    else:
+        assert rc == 1 and "no CPU fallback" in out      # it got past the FASTA stage with mafft's records
+
+
+def test_missing_mafft_panics_like_the_reference(host, tmp_path, monkeypatch):
+    monkeypatch.setenv("PATH", str(tmp_path))           # no mafft anywhere
+    fa = tmp_path / "in.fa"
+    fa.write_text(">a\nACGT\n")
+    rc, out = call(host.odm_run_cli, *argv("-i", str(fa), "-o", str(tmp_path / "o.csv"), "--do-align", "true"))
+    assert rc == 101
+    assert out == 'failed to execute MAFFT: Os { code: 2, kind: NotFound, message: "No such file or directory" }'
+
+
+def test_format_ntthal_input_golden_and_skip_rules(host, golden_dir):
+    """od-msspe/src/delta_g.rs:162-193 (test_format_ntthal_input) through the host's mirror of
+    format_ntthal_input, plus the two skip rules of delta_g.rs:64-73 the reference does not test."""
+    import json
+    import pyoracle
+    g = json.loads((golden_dir / "ntthal_format.json").read_text())
+    primers = "\n".join(g["primers"]).encode()
+    rc, out = call(host.odm_format_ntthal_input, primers, int(g["check_cross_dimers"]), int(g["check_self_dimers"]))
+    assert rc >= 0 and out == g["expected"]
+    assert out.split("\n") == [f"{a},{b}" for a in g["primers"] for b in g["primers"]]    # row-major, a outer
+    # check_cross_dimers = false: nothing at all is sent, self pairs included (delta_g.rs:71-73)
+    assert call(host.odm_format_ntthal_input, primers, 0, 1)[1] == ""
+    # check_self_dimers = false: a == b and a == revcomp(b) are skipped (delta_g.rs:66-69)
+    a = g["primers"][0]
+    trio = [a, pyoracle.reverse_complement(a), g["primers"][1]]
+    rc, out = call(host.odm_format_ntthal_input, "\n".join(trio).encode(), 1, 0)
+    want = [f"{x},{y}" for x in trio for y in trio if not (x == y or pyoracle.reverse_complement(y) == x)]
+    assert out.split("\n") == want and len(want) == 4
