@@ -11,8 +11,11 @@
  *   - every call returns an int status (MSSPE_OK = 0); msspe_last_error(ctx) gives the text;
  *   - plain pointers and sizes only, caller owns every buffer, no exceptions cross the boundary;
  *   - one context per host thread per device; calls on different contexts are concurrent-safe;
- *   - `_dev` entry points take DEVICE pointers and enqueue on the context's HIP stream without
- *     synchronising (graph-capturable); the others take HOST pointers, copy, run and synchronise;
+ *   - `_dev` entry points take DEVICE pointers and enqueue on the context's HIP stream; in the steady
+ *     state they neither allocate nor synchronise, but the FIRST call with a new chemistry / threshold, or
+ *     with a larger problem than any before, builds tables and (re)allocates work buffers, which
+ *     synchronises.  Warm a context up with one call of the final size before capturing a HIP graph.  The
+ *     others take HOST pointers, copy, run and synchronise;
  *   - there is NO CPU fallback: without a usable gfx950 device msspe_create() fails.
  *
  * Oligo encoding on the device: one uint64 per oligo, base p (0-based from the 5' end) in bits
@@ -118,6 +121,30 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
 int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
                       const msspe_chem *chem, float dg_threshold,
                       uint32_t *row_conflicts, uint64_t *bitmap, double *dg, double *tm);
+
+/* The same screen as an edge list (the reference keeps one edge with its dG per conflicting
+ * ordered pair, od-msspe/src/delta_g.rs:33-46, and reads it back through Edge::get_dg(), :10-15).
+ *   _dev: enqueue only.  d_edges[capacity] receives (a, b, raw double dG) in no particular order, *d_count the
+ *         number of conflict edges of the block; a count above the capacity means the list is truncated (the
+ *         first `capacity` to arrive are kept).  d_row_conflicts optional.
+ *   host: whole pool; edges sorted by (a, b) as the reference's nested loops produce them, dg = the value
+ *         get_dg() yields ("%g" -> f32 -> "{:.2}" -> f32).  *count_out = number of conflict edges; when it
+ *         exceeds `capacity` the call returns MSSPE_ERR_CAPACITY with the first `capacity` edges (of the
+ *         arrival order, then sorted) filled in, so the caller can retry with count_out entries. */
+typedef struct {
+    uint32_t a, b;   /* pool indices of the ordered pair */
+    double dg;       /* cal/mol, unrounded */
+} msspe_edge_dev;
+typedef struct {
+    uint32_t a, b;
+    float dg;
+} msspe_edge;
+int msspe_cross_dimer_edges_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k, const msspe_chem *chem,
+                                float dg_threshold, int row0, int row1, int col0, int col1,
+                                uint32_t *d_row_conflicts, msspe_edge_dev *d_edges, uint64_t capacity,
+                                uint64_t *d_count);
+int msspe_cross_dimer_edges(msspe_ctx *ctx, const char *pool_ascii, int n, int k, const msspe_chem *chem,
+                            float dg_threshold, msspe_edge *edges, uint64_t capacity, uint64_t *count_out);
 
 /* Number of pairs the last cross-dimer call routed to the generic (slow) kernel because their
  * DP did not fit the fast kernel's register-resident table. */

@@ -45,7 +45,9 @@ struct ChemEntry {
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
 constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows with the call up to kListCapMax): one launch can never overrun it
-constexpr long kListCapMax = 1L << 30;       // 8 GB per list: 16 launches between flushes (288 GB HBM)
+constexpr long kListCapMax = 1L << 28;       // 2 GB per list (two of them): the stages behind the first run every two launches
+                                             // of 2^27 pairs, so that a list cannot be overrun even if every pair were handed on
+                                             // (6 % are); k_accumulate_overflow checks the counters against it all the same
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace
@@ -76,7 +78,7 @@ struct msspe_ctx {
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
     uint32_t *ovf_count = nullptr;     // list counters of the stages (8): [0] first, [1] second, ...
     long list_cap = 0;                 // entries per hand-over list
-    uint64_t *d_ovf_total = nullptr;
+    uint64_t *d_ovf_total = nullptr;   // [0] pairs handed on so far, [1] != 0: a list counter went past its capacity
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
     uint32_t *d_perm = nullptr, *d_bins = nullptr;
@@ -194,8 +196,8 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
         HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, sizeof(uint32_t) * 8, ctx->stream));
     }
     if (!ctx->d_ovf_total) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, sizeof(uint64_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, sizeof(uint64_t), ctx->stream));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ovf_total, 2 * sizeof(uint64_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, 2 * sizeof(uint64_t), ctx->stream));
     }
     if (!ctx->d_reasons) {
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_reasons, (9 + 1024 + 8) * sizeof(unsigned long long)));
@@ -242,9 +244,16 @@ int ensure_sort(msspe_ctx *ctx, size_t ncols)
     return MSSPE_OK;
 }
 
-__global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total)
+// End of a flush: totals for the statistics, and the check that no stage's list counter went past the
+// capacity of its list (entries beyond it are not stored: the host sizes the flushes so that this cannot
+// happen, and a screen during which it did must not be trusted).
+__global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total, uint32_t cap)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *total += *count;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        total[0] += count[0];
+        for (int q = 0; q < 7; ++q)
+            if (count[q] > cap) total[1] = 1;
+    }
 }
 
 }  // namespace
@@ -394,12 +403,23 @@ int msspe_reset_stream(msspe_ctx *ctx)
     return MSSPE_OK;
 }
 
+// after a synchronisation: did any stage's hand-over list run past its capacity since the last check?
+static int check_list_overrun(msspe_ctx *ctx)
+{
+    if (!ctx->d_ovf_total) return MSSPE_OK;
+    uint64_t flag = 0;
+    HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_ovf_total + 1, sizeof flag, hipMemcpyDeviceToHost));
+    if (!flag) return MSSPE_OK;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total + 1, 0, sizeof flag, ctx->stream));
+    return fail(ctx, MSSPE_ERR_DEVICE, "a hand-over list was overrun: results of the last screen are incomplete");
+}
+
 int msspe_synchronize(msspe_ctx *ctx)
 {
     if (!ctx) return MSSPE_ERR_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MSSPE_OK;
+    return check_list_overrun(ctx);
 }
 
 int msspe_pack_oligos(const char *ascii, int n, int k, uint64_t *packed_out)
@@ -430,10 +450,39 @@ void msspe_unpack_oligo(uint64_t packed, int k, char *ascii_out)
     ascii_out[k] = 0;
 }
 
+static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k, const msspe_chem *chem,
+                            float dg_threshold, int row0, int row1, int col0, int col1,
+                            uint32_t *d_row_conflicts, uint64_t *d_bitmap, double *d_dg, double *d_tm,
+                            EdgeRecord *d_edges, unsigned long long *d_edge_count, unsigned long long edge_cap);
+
 int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                           const msspe_chem *chem, float dg_threshold, int row0, int row1,
                           int col0, int col1, uint32_t *d_row_conflicts, uint64_t *d_bitmap,
                           double *d_dg, double *d_tm)
+{
+    return cross_dimer_impl(ctx, d_pool, n, k, chem, dg_threshold, row0, row1, col0, col1, d_row_conflicts,
+                            d_bitmap, d_dg, d_tm, nullptr, nullptr, 0);
+}
+
+int msspe_cross_dimer_edges_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k, const msspe_chem *chem,
+                                float dg_threshold, int row0, int row1, int col0, int col1,
+                                uint32_t *d_row_conflicts, msspe_edge_dev *d_edges, uint64_t capacity,
+                                uint64_t *d_count)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_count || (capacity && !d_edges)) return fail(ctx, MSSPE_ERR_ARG, "edge list: null count or buffer");
+    static_assert(sizeof(msspe_edge_dev) == sizeof(EdgeRecord), "edge record layouts differ");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint64_t), ctx->stream));
+    return cross_dimer_impl(ctx, d_pool, n, k, chem, dg_threshold, row0, row1, col0, col1, d_row_conflicts,
+                            nullptr, nullptr, nullptr, reinterpret_cast<EdgeRecord *>(d_edges),
+                            reinterpret_cast<unsigned long long *>(d_count), capacity);
+}
+
+static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k, const msspe_chem *chem,
+                            float dg_threshold, int row0, int row1, int col0, int col1,
+                            uint32_t *d_row_conflicts, uint64_t *d_bitmap, double *d_dg, double *d_tm,
+                            EdgeRecord *d_edges, unsigned long long *d_edge_count, unsigned long long edge_cap)
 {
     if (!ctx) return MSSPE_ERR_ARG;
     if (!d_pool || !chem || n < 0) return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry");
@@ -475,6 +524,9 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     sinks.col0 = col0;
     sinks.ncols = ncols;
     sinks.words = words;
+    sinks.edges = d_edges;
+    sinks.edge_count = d_edge_count;
+    sinks.edge_cap = edge_cap;
     GenericDimerArgs g;
     std::memset(&g, 0, sizeof g);
     g.pt = ce->d_pt;
@@ -553,7 +605,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
             g.n_work = kListCap;
             HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
             hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
-                               ctx->d_ovf_total);
+                               ctx->d_ovf_total, (uint32_t)kListCap);
             HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
             return MSSPE_OK;
         }
@@ -595,7 +647,7 @@ int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         g.n_work = kListCap;
         HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
         hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
-                           ctx->d_ovf_total);
+                           ctx->d_ovf_total, (uint32_t)kListCap);
         HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
         return MSSPE_OK;
     };
@@ -687,8 +739,11 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out)
     if (!ctx->d_ovf_total) return MSSPE_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(count_out, ctx->d_ovf_total, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, sizeof(uint64_t), ctx->stream));
+    uint64_t both[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(both, ctx->d_ovf_total, sizeof both, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovf_total, 0, sizeof both, ctx->stream));
+    *count_out = both[0];
+    if (both[1]) return fail(ctx, MSSPE_ERR_DEVICE, "a hand-over list was overrun: results of the last screen are incomplete");
     return MSSPE_OK;
 }
 
@@ -771,6 +826,10 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
         return rc;
     }
     TRY_OR_CLEAN(hipStreamSynchronize(ctx->stream));
+    if ((rc = check_list_overrun(ctx))) {
+        cleanup();
+        return rc;
+    }
     if (row_conflicts)
         TRY_OR_CLEAN(hipMemcpy(row_conflicts, d_rc, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     if (bitmap)
@@ -778,6 +837,73 @@ int msspe_cross_dimer(msspe_ctx *ctx, const char *pool_ascii, int n, int k,
     if (dg) TRY_OR_CLEAN(hipMemcpy(dg, d_dg, sizeof(double) * nn, hipMemcpyDeviceToHost));
     if (tm) TRY_OR_CLEAN(hipMemcpy(tm, d_tm, sizeof(double) * nn, hipMemcpyDeviceToHost));
     cleanup();
+    return MSSPE_OK;
+}
+
+int msspe_cross_dimer_edges(msspe_ctx *ctx, const char *pool_ascii, int n, int k, const msspe_chem *chem,
+                            float dg_threshold, msspe_edge *edges, uint64_t capacity, uint64_t *count_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!pool_ascii || !chem || !count_out || n < 0 || (capacity && !edges))
+        return fail(ctx, MSSPE_ERR_ARG, "null pool/chemistry/count, or a capacity without a buffer");
+    *count_out = 0;
+    if (n == 0) return MSSPE_OK;
+    std::vector<uint64_t> packed((size_t)n);
+    int rc = msspe_pack_oligos(pool_ascii, n, k, packed.data());
+    if (rc) return fail(ctx, rc, rc == MSSPE_ERR_K ? "oligo length must be 1..32"
+                                                   : "pool holds characters other than ACGT");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t *d_pool = nullptr, *d_count = nullptr;
+    msspe_edge_dev *d_edges = nullptr;
+    auto cleanup = [&]() {
+        if (d_pool) (void)hipFree(d_pool);
+        if (d_count) (void)hipFree(d_count);
+        if (d_edges) (void)hipFree(d_edges);
+    };
+#define TRY_OR_CLEAN2(expr)                                        \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) {                                   \
+            cleanup();                                             \
+            return hip_fail(ctx, e__, #expr);                      \
+        }                                                          \
+    } while (0)
+    TRY_OR_CLEAN2(hipMalloc((void **)&d_pool, sizeof(uint64_t) * (size_t)n));
+    TRY_OR_CLEAN2(hipMemcpy(d_pool, packed.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN2(hipMalloc((void **)&d_count, sizeof(uint64_t)));
+    if (capacity) TRY_OR_CLEAN2(hipMalloc((void **)&d_edges, sizeof(msspe_edge_dev) * (size_t)capacity));
+    rc = msspe_cross_dimer_edges_dev(ctx, d_pool, n, k, chem, dg_threshold, 0, n, 0, n, nullptr, d_edges, capacity,
+                                     d_count);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN2(hipStreamSynchronize(ctx->stream));
+    if ((rc = check_list_overrun(ctx))) {
+        cleanup();
+        return rc;
+    }
+    uint64_t count = 0;
+    TRY_OR_CLEAN2(hipMemcpy(&count, d_count, sizeof count, hipMemcpyDeviceToHost));
+    *count_out = count;
+    const size_t have = (size_t)std::min<uint64_t>(count, capacity);
+    std::vector<msspe_edge_dev> raw(have);
+    if (have) TRY_OR_CLEAN2(hipMemcpy(raw.data(), d_edges, sizeof(msspe_edge_dev) * have, hipMemcpyDeviceToHost));
+    cleanup();
+#undef TRY_OR_CLEAN2
+    // the kernels append in no particular order: sort by (a, b) as the reference's nested loops emit them
+    std::sort(raw.begin(), raw.end(), [](const msspe_edge_dev &x, const msspe_edge_dev &y) {
+        return x.a != y.a ? x.a < y.a : x.b < y.b;
+    });
+    for (size_t e = 0; e < have; ++e) {
+        edges[e].a = raw[e].a;
+        edges[e].b = raw[e].b;
+        // what Edge::get_dg() returns: the %g text as f32, stored as "{:.2}", parsed again (delta_g.rs:10-15, 33-46)
+        edges[e].dg = round_fixed_f32((double)round_g_f32(raw[e].dg), 2);
+    }
+    if (count > capacity)
+        return fail(ctx, MSSPE_ERR_CAPACITY, "edge list: " + std::to_string(count) + " conflict edges, capacity " +
+                                                 std::to_string(capacity));
     return MSSPE_OK;
 }
 

@@ -11,6 +11,13 @@
 
 namespace msspe {
 
+// One conflict edge as the kernels emit it: pool indices of the ordered pair and the raw double dG (the
+// reference's stored text value is msspe_round_fixed_f32(msspe_round_g_f32(dg), 2), applied by the host).
+struct EdgeRecord {
+    uint32_t a, b;
+    double dg;
+};
+
 // Where the results of one ordered pair go (all pointers optional, device memory).
 struct PairSinks {
     uint32_t *row_conflicts;   // [n]            += 1 per conflicting column
@@ -18,7 +25,25 @@ struct PairSinks {
     double *dg;                // [(row1-row0) * (col1-col0)]
     double *tm;                // [(row1-row0) * (col1-col0)]
     int row0, col0, ncols, words;
+    EdgeRecord *edges;         // conflict edges (i, j, dG), at most edge_cap of them are stored ...
+    unsigned long long *edge_count;   // ... and every one is counted here (a count above the capacity = truncated)
+    unsigned long long edge_cap;
 };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void sink_edge(const PairSinks &s, int row, int col, double dG)
+{
+    if (!s.edge_count) return;
+    const unsigned long long at = atomicAdd(s.edge_count, 1ull);
+    if (s.edges && at < s.edge_cap) {
+        EdgeRecord e;
+        e.a = (uint32_t)row;
+        e.b = (uint32_t)col;
+        e.dg = dG;
+        s.edges[at] = e;
+    }
+}
+#endif
 
 // Generic dense-DP dimer kernel.
 //   list != nullptr : work item w = ordered pair (list[w].x, list[w].y) of pool indices

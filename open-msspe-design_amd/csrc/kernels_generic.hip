@@ -21,6 +21,7 @@ __device__ __forceinline__ void sink_pair(const PairSinks &s, const ThalConsts &
         if (s.bitmap)
             atomicOr((unsigned long long *)&s.bitmap[r * (size_t)s.words + (q >> 6)],
                      1ull << (q & 63));
+        sink_edge(s, row, col, o.dG);
     }
 }
 

@@ -452,6 +452,7 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
         if (hit && a.sinks.bitmap)
             atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
                      1ull << (ocol & 63));
+        if (hit) sink_edge(a.sinks, row, col, r.dG);
         if (lane == 0 && a.sinks.row_conflicts && bits)
             atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
         if (live) {
@@ -577,6 +578,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
                     if (a.sinks.bitmap)
                         atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
                                  1ull << (ocol & 63));
+                    sink_edge(a.sinks, (int)pr.x, (int)pr.y, r.dG);
                 }
             }
         }

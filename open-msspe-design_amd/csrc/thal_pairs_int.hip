@@ -528,6 +528,7 @@ __device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, in
     if (hit && a.f.sinks.bitmap)
         atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
                  1ull << (ocol & 63));
+    if (hit) sink_edge(a.f.sinks, row, col, r.r.dG);
     if (a.f.sinks.row_conflicts) {
         if (same_row) {
             const unsigned long long bits = __ballot(hit);

@@ -545,6 +545,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     if (hit && a.f.sinks.bitmap)
         atomicOr((unsigned long long *)&a.f.sinks.bitmap[orow * (size_t)a.f.sinks.words + (ocol >> 6)],
                  1ull << (ocol & 63));
+    if (hit) sink_edge(a.f.sinks, row, col, r.r.dG);
     if (a.f.sinks.row_conflicts) {
         const unsigned long long bits = __ballot(hit);
         if (lane == 0 && bits) atomicAdd(&a.f.sinks.row_conflicts[row], (unsigned)__popcll(bits));

@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
         if (hit && a.sinks.bitmap)
             atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
                      1ull << (ocol & 63));
+        if (hit) sink_edge(a.sinks, row, col, r.dG);
         if (a.sinks.row_conflicts) {
             const unsigned long long bits = __ballot(hit);
             if (lane == 0 && bits) atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));

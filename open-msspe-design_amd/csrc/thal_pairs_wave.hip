@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
                         atomicOr((unsigned long long *)&a.sinks.bitmap[orow * (size_t)a.sinks.words + (ocol >> 6)],
                                  1ull << (ocol & 63));
                     if (a.sinks.row_conflicts) atomicAdd(&a.sinks.row_conflicts[row], 1u);
+                    sink_edge(a.sinks, row, col, r.dG);
                 }
                 if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
                 if (a.sinks.tm) a.sinks.tm[orow * (size_t)a.sinks.ncols + ocol] = r.t;

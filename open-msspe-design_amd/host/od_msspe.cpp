@@ -471,24 +471,28 @@ ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
     const int n = (int)g.nodes.size(), k = (int)g.nodes[0].size();
     std::string flat;
     for (const auto &p : g.nodes) flat += p;
-    const size_t words = ((size_t)n + 63) / 64;
-    std::vector<uint64_t> bitmap((size_t)n * words);
     auto two = [](float v) {   // ntthal receives "{:.2}" strings of the f32 options (delta_g.rs:98-106)
         char b[64];
         std::snprintf(b, sizeof b, "%.2f", (double)v);
         return std::strtod(b, nullptr);
     };
     msspe_chem chem{two(opts.mv), two(opts.dv), two(opts.dntp), two(opts.conc), two(opts.t), 30};
-    const int rc = msspe_cross_dimer(eng.ctx(), flat.data(), n, k, &chem, opts.dg, nullptr,
-                                     bitmap.data(), nullptr, nullptr);
+    // the conflict edges as a list (about 0.5 % of the ordered pairs at the default threshold), not the
+    // dense n x n bitmap; if the first guess is too small the call says how many there are
+    std::vector<msspe_edge> edges((size_t)std::max<uint64_t>(4096, (uint64_t)n * (uint64_t)n / 64));
+    uint64_t count = 0;
+    int rc = msspe_cross_dimer_edges(eng.ctx(), flat.data(), n, k, &chem, opts.dg, edges.data(), edges.size(), &count);
+    if (rc == MSSPE_ERR_CAPACITY) {
+        edges.resize((size_t)count);
+        rc = msspe_cross_dimer_edges(eng.ctx(), flat.data(), n, k, &chem, opts.dg, edges.data(), edges.size(), &count);
+    }
     if (rc) eng.fail(rc);
-    for (int a = 0; a < n; ++a)
-        for (int b = 0; b < n; ++b) {
-            if (!((bitmap[(size_t)a * words + (size_t)(b >> 6)] >> (b & 63)) & 1ull)) continue;
-            // delta_g.rs:66-69: pairs never sent to ntthal when self-dimer checking is off
-            if (!ntthal_pair_sent(g.nodes[(size_t)a], g.nodes[(size_t)b], cfg)) continue;
-            g.edges[g.nodes[(size_t)a]].insert(g.nodes[(size_t)b]);
-        }
+    for (uint64_t e = 0; e < count; ++e) {
+        const std::string &a = g.nodes[edges[(size_t)e].a], &b = g.nodes[edges[(size_t)e].b];
+        // delta_g.rs:66-69: pairs never sent to ntthal when self-dimer checking is off
+        if (!ntthal_pair_sent(a, b, cfg)) continue;
+        g.edges[a].insert(b);
+    }
     return g;
 }
 

@@ -16,6 +16,7 @@ EXPORTS = [
     "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
+    "msspe_cross_dimer_edges_dev", "msspe_cross_dimer_edges",
     "msspe_last_overflow_pairs", "msspe_pair_stage_stats", "msspe_pair_stage_samples", "msspe_host_pair_tables", "msspe_host_split_tables", "msspe_device_put_rows", "msspe_segment_coverage", "msspe_segment_coverage_dev",
     "msspe_device_put", "msspe_device_free", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
@@ -97,6 +98,10 @@ def load_library() -> C.CDLL:
                                         C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.msspe_cross_dimer.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
                                     vp, vp, vp, vp]
+    L.msspe_cross_dimer_edges.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float, vp,
+                                          C.c_uint64, C.POINTER(C.c_uint64)]
+    L.msspe_cross_dimer_edges_dev.argtypes = [vp, u64p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_uint64, vp]
     L.msspe_last_overflow_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.msspe_pair_stage_stats.argtypes = [vp, C.POINTER(C.c_uint64)]   # out[16]
     L.msspe_pair_stage_samples.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]
@@ -226,6 +231,22 @@ class Engine:
             bm.ctypes.data if want_bitmap else None, dg.ctypes.data if want_dg else None,
             tm.ctypes.data if want_tm else None))
         return {"row_conflicts": rc_, "bitmap": bm, "dg": dg, "tm": tm}
+
+    def cross_dimer_edges(self, pool, chem: Chem | None = None, threshold: float = -9000.0, capacity: int = 1 << 20):
+        """Edge list of the whole pool: (edges structured array [a, b, dg], count); raises MsspeError
+        (MSSPE_ERR_CAPACITY, .count = edges needed) when the capacity is too small."""
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.ntthal()
+        edges = np.zeros(capacity, dtype=np.dtype([("a", np.uint32), ("b", np.uint32), ("dg", np.float32)]))
+        count = C.c_uint64()
+        rc = self.L.msspe_cross_dimer_edges(self.ptr, buf, n, k, C.byref(chem), C.c_float(threshold),
+                                            edges.ctypes.data, capacity, C.byref(count))
+        if rc:
+            err = MsspeError(rc, self.L.msspe_last_error(self.ptr).decode())
+            err.count = int(count.value)
+            err.edges = edges
+            raise err
+        return edges[:count.value], int(count.value)
 
     def cross_dimer_dev(self, d_pool: int, n: int, k: int, chem: Chem, threshold: float,
                         rows: tuple[int, int], cols: tuple[int, int], d_row_conflicts: int = 0,

@@ -413,3 +413,30 @@ def test_long_oligo_stage_equals_generic_kernel(m, oracle, oracle_tables, monkey
             np.testing.assert_array_equal(sub["tm"][q, len(rows):], tt[0, 1:])
     finally:
         e.close()
+
+
+def test_edge_list_output(m, oracle, oracle_tables):
+    """msspe_cross_dimer_edges: (a, b, dG) per conflicting ordered pair, sorted like the reference's nested
+    loops emit them, dG = what Edge::get_dg() returns ("%g" -> f32 -> "{:.2}" -> f32, delta_g.rs:10-15,
+    33-46); a capacity that is too small is reported with the count needed."""
+    pool = m.synth.pool_strings(m.synth.random_pool(400, 13, seed=5))
+    thr = -7000.0
+    eng = m.Engine(0)
+    try:
+        edges, count = eng.cross_dimer_edges(pool, m.Chem.ntthal(), thr, capacity=1 << 16)
+        dense = eng.cross_dimer(pool, m.Chem.ntthal(), thr, want_dg=True)
+        with pytest.raises(m.MsspeError) as e:
+            eng.cross_dimer_edges(pool, m.Chem.ntthal(), thr, capacity=7)
+        assert e.value.code == 5 and e.value.count == count           # MSSPE_ERR_CAPACITY + edges needed
+        assert np.count_nonzero(e.value.edges["a"] | e.value.edges["b"]) >= 6    # the first 7 are filled in
+    finally:
+        eng.close()
+    _, dg, cf, _ = oracle.pool_pairs(oracle_tables, pool, oracle.ntthal_args(), thr)
+    want = np.argwhere(cf.astype(bool))                                # row-major = sorted by (a, b)
+    assert count == len(want) == int(dense["row_conflicts"].sum()) and count > 100
+    np.testing.assert_array_equal(np.stack([edges["a"], edges["b"]], 1), want)
+    for q in range(0, count, 7):
+        a, b = want[q]
+        first = oracle.round_g_f32(float(dg[a, b]))
+        assert edges["dg"][q] == np.float32(oracle.round_fixed_f32(float(first), 2))
+        assert edges["dg"][q] < np.float32(thr)
