@@ -12,7 +12,12 @@ One check = one ordered pair.  N = 1: the 65,536-primer pool of BASELINE.md sect
 (4.29e9 checks).  N > 1: the pool grows with sqrt(N) so that every rank keeps 4.29e9 checks
 ("weak"); each rank owns n/N candidates, one RCCL all-gather assembles the packed pool, each rank
 screens its row block against all columns, one RCCL all-reduce merges the per-primer conflict
-counts.  Prints ONE JSON line on rank 0.
+counts.  `--config pool1m` is the strong-scaling form: BASELINE.json configs[3], the
+1,048,576-candidate pool, cut into N row blocks (1.1e12 checks in total whatever N is).
+Prints ONE JSON line on rank 0.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N ranks itself with torch.distributed.run as a
+child process, before this process touches the GPU, and exits with the child's status.
 """
 from __future__ import annotations
 
@@ -50,6 +55,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pool", type=int, default=0, help="override the pool size (default 65536*sqrt(N))")
+    ap.add_argument("--config", choices=["headline", "pool1m"], default="headline",
+                    help="headline: 65,536 primers per GPU-equivalent (weak); pool1m: 1,048,576 primers in total (strong)")
+    ap.add_argument("--stage-a", dest="stage_a", action="store_true", default=None,
+                    help="also time stage A on 10,000 x 30 kb synthetic genomes (default: on at N = 1)")
+    ap.add_argument("--no-stage-a", dest="stage_a", action="store_false")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -91,9 +101,58 @@ def cpu_baseline(pool_ascii: np.ndarray, seconds: float, gpu_bitmap_rows: np.nda
             "decisions_equal_gpu": agree}
 
 
+def stage_a_line(eng, device):
+    """Stage A (k-mer candidates, the HBM-bound part of the path) on BASELINE.json configs[2]'s shape:
+    10,000 synthetic aligned genomes of 30 kb, both directions, alignment resident in HBM.  Algorithmic
+    bytes per direction: 100 B of window per segment read, 38 instances x 12 B written and
+    sorted once, 38 x 4 B of count updates when the segment is covered."""
+    n_rows, length = 10000, 30000
+    genomes = msspe_amd.synth.aligned_genomes(n_rows, length)
+    d = torch.from_numpy(genomes).to(device)
+    opt = msspe_amd.KmerOpt(500, 250, 50, K, 1000, 10)
+    out = {}
+    for direction in (0, 1):
+        eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=n_rows, seq_len=length)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    winners = 0
+    for _ in range(reps):
+        for direction in (0, 1):
+            w, _f = eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=n_rows, seq_len=length)
+            winners += len(w)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (2 * reps) * 1e3
+    segments = n_rows * ((length - 500) // 250 + 1)
+    alg_bytes = segments * (100.0 + 38 * 12.0 + 38 * 4.0)
+    out.update({"workload": f"{n_rows} synthetic aligned genomes x {length} columns, k = {K}, both directions",
+                "ms_per_direction": ms, "winners_per_direction": winners / (2 * reps),
+                "algorithmic_bytes_per_direction": alg_bytes,
+                "GBps": alg_bytes / (ms * 1e-3) / 1e9,
+                "frac_of_6.29TBps_copy_ceiling": alg_bytes / (ms * 1e-3) / 6.29e12,
+                "note": "host wall time per direction incl. the greedy loop's dependent launches (launch-latency "
+                        "bound, not bandwidth bound: see DESIGN.md 4.3)"})
+    return out
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with no launcher: start N ranks as a CHILD process (never exec from a
+    process that may have touched the GPU; this one has not) and hand its exit status on."""
+    import subprocess
+    port = 29500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(respawn_under_launcher(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # MSSPE_BENCH_BACKEND=gloo + MSSPE_BENCH_DEVICE=0 rehearses the N > 1 path with several ranks
@@ -107,22 +166,27 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    n_gpus = max(args.gpus, world)
+    n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n = args.pool if args.pool else pool_size_for(world)
-    n = (n // (64 * world)) * (64 * world)
-    shard = n // world
-    r0, r1 = shard_bounds(n, world, rank)
-    words = n // 64
+    strong = args.config == "pool1m"
+    n = args.pool if args.pool else (1 << 20 if strong else pool_size_for(world))
+    if not args.pool:
+        n = (n // (64 * world)) * (64 * world)
+    r0, r1 = shard_bounds(n, world, rank)       # row blocks may differ by one row (any n, any N)
+    shard = r1 - r0
+    words = (n + 63) // 64
 
     # synthetic pool (PCG64 seed 20260630); every rank uploads only the candidates it "produced"
     pool_ascii = msspe_amd.synth.random_pool(n, K)
     packed = msspe_amd.pack_oligos(pool_ascii)
     d_shard = torch.from_numpy(packed[r0:r1].view(np.int64).copy()).to(dev)
     d_conf = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_bitmap = torch.zeros((shard, words), dtype=torch.int64, device=dev)
+    # the conflict bitmap of a rank's row block: 8 B per 64 columns; at 1M candidates that is 137 GB for a
+    # single rank, so the largest pools run with counts only (SURVEY.md 7 "output volume")
+    want_bitmap = float(shard) * words * 8 <= 64e9
+    d_bitmap = torch.zeros((shard, words), dtype=torch.int64, device=dev) if want_bitmap else None
 
     eng = msspe_amd.Engine(local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -153,6 +217,12 @@ def main():
     eng.profile_enable(False)
     overflow = eng.last_overflow_pairs()
     stage = eng.pair_stage_stats()
+    # per-rank time in the dominant kernel (HIP events on the engine's stream): a load imbalance between
+    # the row blocks would show as a spread here
+    km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    km_lo, km_hi = km.clone(), km.clone()
+    all_reduce(km_lo, dist.ReduceOp.MIN)
+    all_reduce(km_hi, dist.ReduceOp.MAX)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     all_reduce(t, dist.ReduceOp.MAX)
@@ -180,14 +250,24 @@ def main():
                 traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        int_stage = os.environ.get("MSSPE_PAIR_KERNEL", "") != "f64"
+        # counters come from a separate rocprofv3 --pmc run (profiles/): they are IMPORTED, not measured
+        # in this run, and say so; only launches / avg_launch_ms / achieved / frac below are live
         executed = None
         pf = ROOT / "profiles" / "pmc_latest.json"
         if pf.exists():
             try:
                 executed = json.loads(pf.read_text())
+                executed["imported_from"] = "profiles/pmc_latest.json"
             except Exception:
                 executed = None
+        traffic_src = None
+        if traffic is not None:
+            try:
+                tj = json.loads(tf.read_text())
+                traffic_src = {"imported_from": "profiles/traffic_latest.json", "kernel": tj.get("kernel"),
+                               "commit": tj.get("commit"), "round": tj.get("round")}
+            except Exception:
+                traffic_src = {"imported_from": "profiles/traffic_latest.json"}
         roofline = {
             "bound": "valu",
             "note": ("vector-ALU bound DP: neither HBM nor MFMA binds it (SURVEY.md 8d). achieved = the "
@@ -195,16 +275,19 @@ def main():
                      "priced against the FP64 vector peak; the kernel itself runs the recurrence on exact "
                      "int32 (see executed) and replays the optimal path in f64. hbm gives algorithmic "
                      "bytes/s as the north star asks"),
-            "kernel": "k_pairs_int" if int_stage else "k_pairs_fast",
+            "kernel": "k_pairs_row",
             "achieved": kernel_checks_per_s * F64_OPS_PER_CHECK / 1e12,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": kernel_checks_per_s * F64_OPS_PER_CHECK / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "f64_ops_per_check": F64_OPS_PER_CHECK,
             "launches": launches,
             "avg_launch_ms": per_launch_s * 1e3,
             "checks_per_launch": per_launch_checks,
+            "kernel_ms_per_rank": {"min": float(km_lo.item()) / args.steps, "max": float(km_hi.item()) / args.steps,
+                                   "note": "dominant kernel, per step, over the ranks"},
             "executed": executed,
             "retried_in_list_mode": overflow / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
             "flagged_ties": stage["deferred"] / max(checks_rank * (args.steps + args.warmup) / args.steps, 1.0),
@@ -215,16 +298,20 @@ def main():
                     "algorithmic_bytes_per_check": bytes_per_launch / per_launch_checks},
         }
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:      # rank 0, every N: rows 0.. belong to rank 0's block
             cpu = cpu_baseline(pool_ascii, args.cpu_seconds,
-                               d_bitmap[:4096].cpu().numpy().view(np.uint64))
+                               d_bitmap[:min(4096, shard)].cpu().numpy().view(np.uint64) if want_bitmap else None)
+        stage_a = None
+        if args.stage_a if args.stage_a is not None else (world == 1 and not args.pool):
+            stage_a = stage_a_line(eng, dev)
         out = {
             "metric": "primer-pair thermo checks/sec (all-pairs cross-dimer)",
             "value": value, "unit": "checks/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "i32+f64", "data": "synthetic",
-            "config": {"workload": f"cross-dimer all ordered pairs of {n} random 13-mers "
+            "config": {"workload": ("BASELINE configs[3], strong scaling: " if strong else "") +
+                                   f"cross-dimer all ordered pairs of {n} random 13-mers "
                                    f"({checks_per_step:.3g} checks/step), thal ANY at od-msspe defaults "
                                    f"(mv 50, dv 3, dNTP 0, 250 nM, 25 C), threshold -9000 cal/mol",
                        "pool": n, "kmer_size": K, "checks_per_step": checks_per_step,
@@ -234,6 +321,7 @@ def main():
                        "overflow_pairs_per_step": overflow / max(args.steps + args.warmup, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "stage_a": stage_a,
         }
         print(json.dumps(out))
     if world > 1:

@@ -22,8 +22,9 @@ def _bench_line(cmd, env):
     return json.loads(lines[0])
 
 
-def test_two_ranks_equal_one_rank():
-    common = ["--steps", "1", "--warmup", "1", "--pool", "4000", "--no-cpu-baseline"]
+@pytest.mark.parametrize("pool", ["4000", "3001"])        # 3001: odd, the two row blocks differ by one row
+def test_two_ranks_equal_one_rank(pool):
+    common = ["--steps", "1", "--warmup", "1", "--pool", pool, "--no-cpu-baseline"]
     env = dict(os.environ)
     one = _bench_line([sys.executable, "bench.py", "--gpus", "1"] + common, env)
     env2 = dict(env, MSSPE_BENCH_BACKEND="gloo", MSSPE_BENCH_DEVICE="0")
@@ -37,3 +38,13 @@ def test_two_ranks_equal_one_rank():
     assert one["config"]["conflicts"] > 0
     assert two["cpu_baseline"] is None          # rank 0 at N = 1 only
     assert two["value"] > 0 and two["roofline"]["launches"] >= 1
+    km = two["roofline"]["kernel_ms_per_rank"]
+    assert 0 < km["min"] <= km["max"]
+
+
+def test_gpus_flag_must_match_the_launcher():
+    """`--gpus 2` inside a one-rank launch is refused instead of reporting a one-GPU number as two."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--pool", "512",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
