@@ -1024,7 +1024,10 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         h.wsS = ctx->wsS;
         h.wsH = ctx->wsH;
         h.ws_lanes = kGenericLanes;
-        HIP_TRY(ctx, launch_hairpin_generic(h, ctx->stream));
+        // one wave per oligo with the DP planes in LDS (thal_hairpin_wave.hip); the one-lane kernel over a
+        // global workspace stays as the reference implementation behind option "force_generic"
+        if (ctx->opt.force_generic || k > 32) HIP_TRY(ctx, launch_hairpin_generic(h, ctx->stream));
+        else HIP_TRY(ctx, launch_hairpin_wave(h, ctx->n_cu, ctx->stream));
     }
     return MSSPE_OK;
 }

@@ -80,6 +80,8 @@ struct HairpinArgs {
     size_t ws_lanes;
 };
 hipError_t launch_hairpin_generic(const HairpinArgs &a, hipStream_t stream);
+// The same recurrence with one wave per oligo and the planes in LDS (thal_hairpin_wave.hip), k <= 32.
+hipError_t launch_hairpin_wave(const HairpinArgs &a, int n_cu, hipStream_t stream);
 
 // oligotm + GC%: one lane per oligo.
 hipError_t launch_oligo_tm(const uint64_t *pool, int n, int k, double dna_conc, double mv,

@@ -451,6 +451,63 @@ struct HairpinCtx {
         return bpmask;
     }
 
+    // thal.c fillMatrix2() for ONE cell (maxTM2, CBI, calc_hairpin): reads cells strictly inside (i, j)
+    // and the cell itself, writes the cell.
+    __device__ void fill_cell(int i, int j)
+    {
+        if (!isfinite(mh(i, j))) return;
+        {   // maxTM2()
+            double S0 = ms(i, j), H0 = mh(i, j);
+            const double T0 = tau(H0, S0);
+            double S1 = (ms(i + 1, j - 1) + stS(i, j));
+            double H1 = (mh(i + 1, j - 1) + stH(i, j));
+            const double T1 = tau(H1, S1);
+            if (S1 < kMinEntropyCutoff) {
+                S1 = kMinEntropy;
+                H1 = 0.0;
+            }
+            if (S0 < kMinEntropyCutoff) {
+                S0 = kMinEntropy;
+                H0 = 0.0;
+            }
+            if (T1 > T0) mset(i, j, S1, H1);
+            else mset(i, j, S0, H0);
+        }
+        double oS = -1.0, oH = INFINITY;
+        inner_loops(i, j, oS, oH, 0);
+        oS = -1.0;
+        oH = INFINITY;
+        closure(i, j, oS, oH, 0);
+        if (isfinite(oH)) {
+            if (oS < kMinEntropyCutoff) {
+                oS = kMinEntropy;
+                oH = 0.0;
+            }
+            mset(i, j, oS, oH);
+        }
+    }
+
+    // thal.c drawHairpin()'s totals from the filled planes (terminal pass, traceback, Tm)
+    __device__ void finish(ThalOut &o)
+    {
+        const int n = s.len;
+        terminal_bp();
+        const double mh_ = h5(n), ms_ = s5(n);
+        o.none = 1;
+        o.t = 0.0;
+        o.dS = o.dH = o.dG = 0.0;
+        o.n_pairs = 0;
+        if (!isfinite(mh_)) return;
+        const uint64_t bp = traceback();
+        const int N = __popcll(bp & ((1ull << (n - 1)) - 1));   // drawHairpin: i = 1 .. len-1
+        o.n_pairs = __popcll(bp) / 2;
+        o.none = 0;
+        o.t = (mh_ / (ms_ + (((N / 2) - 1) * c.salt))) - kAbsZero;
+        o.dH = mh_;
+        o.dS = ms_ + (((N / 2) - 1) * c.salt);
+        o.dG = mh_ - (c.temp_k * (ms_ + (((N / 2) - 1) * c.salt)));
+    }
+
     __device__ void run(ThalOut &o)
     {
         const int n = s.len;

@@ -440,3 +440,36 @@ def test_edge_list_output(m, oracle, oracle_tables):
         first = oracle.round_g_f32(float(dg[a, b]))
         assert edges["dg"][q] == np.float32(oracle.round_fixed_f32(float(first), 2))
         assert edges["dg"][q] < np.float32(thr)
+
+
+@pytest.mark.parametrize("k,n", [(13, 6000), (16, 1500), (20, 1200), (24, 800), (28, 500), (32, 400)])
+def test_hairpin_wave_kernel_bit_exact(m, oracle, oracle_tables, k, n):
+    """HAIRPIN_TH (primer.rs:104-106 -> Primer3 thal type 4) from the wave-per-oligo kernel with its planes
+    in LDS: 10,400 oligos over six lengths, random ones plus designed stem-loops (a stem of 4..7 pairs
+    around loops of 3..6 bases at several offsets), bit-exact against the oracle and against the
+    one-lane kernel over a global workspace (option force_generic)."""
+    rng = np.random.default_rng(1000 + k)
+    pool = m.synth.pool_strings(m.synth.random_pool(n, k, seed=3000 + k))
+    for q in range(n // 4):                                   # every fourth oligo: a designed hairpin
+        stem = int(rng.integers(4, 8))
+        loop = int(rng.integers(3, 7))
+        if 2 * stem + loop > k:
+            stem = (k - loop) // 2
+        left = "".join("ACGT"[x] for x in rng.integers(0, 4, stem))
+        mid = "".join("ACGT"[x] for x in rng.integers(0, 4, loop))
+        core = left + mid + oracle.reverse_complement(left)
+        pad = k - len(core)
+        off = int(rng.integers(0, pad + 1))
+        flank = "".join("ACGT"[x] for x in rng.integers(0, 4, pad))
+        pool[4 * q] = flank[:off] + core + flank[off:]
+    eng = m.Engine(0)
+    try:
+        got = eng.oligo_stats(pool)["hairpin"]
+        eng.set_option("force_generic", 1)
+        slow = eng.oligo_stats(pool)["hairpin"]
+    finally:
+        eng.close()
+    ref = oracle.check_primers(oracle_tables, pool)["hairpin_th"]
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(got, slow)
+    assert (got > 0).sum() >= n // 8                           # the designed ones do fold
