@@ -257,6 +257,23 @@ int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **devi
  * host never builds the rectangular copy. */
 int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
                           size_t row_len, int pad, void **device_out);
+/* The alignment in its compact device form: 2-bit bases + 1 validity bit per column (SURVEY.md 2.2, 8f-3;
+ * replaces the per-window char vectors of od-msspe/src/main.rs:163-235).  A packed row is
+ * msspe_packed_row_words(row_len) uint64: first (row_len + 31) / 32 words of bases (A 0, C 1, G 2, T 3; column
+ * c in bits [2 (c % 32), +1] of word c / 32), then (row_len + 63) / 64 words of validity bits (1 = A / C / G / T;
+ * '-', N, IUPAC codes and the padding of short rows are 0, which invalidates every k-mer that covers them,
+ * main.rs:167).  msspe_device_put_rows_packed uploads the rows 16 MB at a time and packs each chunk on the
+ * device; the *_packed_dev entry points are msspe_kmer_candidates_dev / msspe_segment_coverage_dev on that form
+ * (same outputs; 3/8 of the bytes resident and read). */
+size_t msspe_packed_row_words(size_t seq_len);
+int msspe_device_put_rows_packed(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                                 size_t row_len, void **device_out);
+int msspe_kmer_candidates_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                     const msspe_kmer_opt *opt, int direction,
+                                     uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out);
+int msspe_segment_coverage_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                      const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                                      const uint64_t *rev_words, int n_rev, uint8_t *hit_out);
 int msspe_device_free(msspe_ctx *ctx, void *device);
 
 

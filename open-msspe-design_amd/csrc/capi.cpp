@@ -1081,11 +1081,30 @@ int msspe_kmer_candidates_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq, 
         return fail(ctx, MSSPE_ERR_ARG, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::string err;
-    const int rc = ctx->kmer.run(d_seqs, n_seq, seq_len, *opt, direction, words_out, freq_out,
+    const SeqView view{d_seqs, nullptr, seq_len};
+    const int rc = ctx->kmer.run(view, n_seq, seq_len, *opt, direction, words_out, freq_out,
                                  capacity, n_out, ctx->stream, err);
     if (rc) return fail(ctx, rc, err);
     return MSSPE_OK;
 }
+
+int msspe_kmer_candidates_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                     const msspe_kmer_opt *opt, int direction, uint64_t *words_out,
+                                     uint32_t *freq_out, int capacity, int *n_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_packed || !opt || !words_out || !freq_out || !n_out || capacity < 0)
+        return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const SeqView view{nullptr, d_packed, seq_len};
+    const int rc = ctx->kmer.run(view, n_seq, seq_len, *opt, direction, words_out, freq_out,
+                                 capacity, n_out, ctx->stream, err);
+    if (rc) return fail(ctx, rc, err);
+    return MSSPE_OK;
+}
+
+size_t msspe_packed_row_words(size_t seq_len) { return SeqView::row_words(seq_len); }
 
 int msspe_kmer_candidates(msspe_ctx *ctx, const uint8_t *seqs, int n_seq, size_t seq_len,
                           const msspe_kmer_opt *opt, int direction, uint64_t *words_out,
@@ -1114,7 +1133,24 @@ int msspe_segment_coverage_dev(msspe_ctx *ctx, const uint8_t *d_seqs, int n_seq,
         return fail(ctx, MSSPE_ERR_ARG, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::string err;
-    const int rc = ctx->kmer.coverage(d_seqs, n_seq, seq_len, *opt, fwd_words, n_fwd, rev_words, n_rev,
+    const SeqView view{d_seqs, nullptr, seq_len};
+    const int rc = ctx->kmer.coverage(view, n_seq, seq_len, *opt, fwd_words, n_fwd, rev_words, n_rev,
+                                      hit_out, ctx->stream, err);
+    if (rc) return fail(ctx, rc, err);
+    return MSSPE_OK;
+}
+
+int msspe_segment_coverage_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                      const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
+                                      const uint64_t *rev_words, int n_rev, uint8_t *hit_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_packed || !opt || !hit_out || n_fwd < 0 || n_rev < 0 || (n_fwd && !fwd_words) || (n_rev && !rev_words))
+        return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::string err;
+    const SeqView view{nullptr, d_packed, seq_len};
+    const int rc = ctx->kmer.coverage(view, n_seq, seq_len, *opt, fwd_words, n_fwd, rev_words, n_rev,
                                       hit_out, ctx->stream, err);
     if (rc) return fail(ctx, rc, err);
     return MSSPE_OK;
@@ -1152,8 +1188,25 @@ int msspe_device_put(msspe_ctx *ctx, const void *host, size_t bytes, void **devi
     return MSSPE_OK;
 }
 
+static int put_rows_impl(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                         size_t row_len, int pad, bool packed, void **device_out);
+
 int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
                           size_t row_len, int pad, void **device_out)
+{
+    return put_rows_impl(ctx, rows, row_bytes, n_rows, row_len, pad, false, device_out);
+}
+
+int msspe_device_put_rows_packed(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                                 size_t row_len, void **device_out)
+{
+    return put_rows_impl(ctx, rows, row_bytes, n_rows, row_len, '-', true, device_out);
+}
+
+// packed: the ASCII rows only pass through two 16 MB device chunks; each chunk is packed on the device
+// (k_pack_rows: 2-bit bases + validity bit, 3/8 of a byte per column) behind its copy, on the copy stream
+static int put_rows_impl(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
+                         size_t row_len, int pad, bool packed, void **device_out)
 {
     if (!ctx) return MSSPE_ERR_ARG;
     if (!device_out || n_rows < 0 || (n_rows && (!rows || !row_bytes))) return fail(ctx, MSSPE_ERR_ARG, "null argument");
@@ -1161,7 +1214,8 @@ int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t 
     for (int r = 0; r < n_rows; ++r)
         if (row_bytes[r] > row_len || (row_bytes[r] && !rows[r])) return fail(ctx, MSSPE_ERR_ARG, "row longer than row_len");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t total = row_len * (size_t)n_rows;
+    const size_t row_out = packed ? SeqView::row_words(row_len) * sizeof(uint64_t) : row_len;
+    const size_t total = row_out * (size_t)n_rows;
     char *d = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&d, total ? total : 1));
     if (!total) {
@@ -1173,11 +1227,13 @@ int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t 
     const size_t rows_per_chunk = std::max<size_t>(1, (size_t)(16u << 20) / std::max<size_t>(row_len, 1));
     const size_t chunk_bytes = rows_per_chunk * row_len;
     char *stage[2] = {nullptr, nullptr};
+    char *dchunk[2] = {nullptr, nullptr};   // packed: device landing zone of the ASCII chunk
     hipEvent_t drained[2] = {nullptr, nullptr};
     hipStream_t copy = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking);
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipHostMalloc((void **)&stage[b], chunk_bytes, hipHostMallocDefault);
+        if (e == hipSuccess && packed) e = hipMalloc((void **)&dchunk[b], chunk_bytes);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&drained[b], hipEventDisableTiming);
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -1203,13 +1259,21 @@ int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t 
                 pool.emplace_back(fill, r0 + (r1 - r0) * t / n_threads, r0 + (r1 - r0) * (t + 1) / n_threads);
             for (auto &th : pool) th.join();
         }
-        e = hipMemcpyAsync(d + r0 * row_len, buf, (r1 - r0) * row_len, hipMemcpyHostToDevice, copy);
+        if (packed) {
+            e = hipMemcpyAsync(dchunk[turn], buf, (r1 - r0) * row_len, hipMemcpyHostToDevice, copy);
+            if (e == hipSuccess)
+                e = launch_pack_rows((const uint8_t *)dchunk[turn], (int)(r1 - r0), row_len,
+                                     (uint64_t *)(d + r0 * row_out), copy);
+        } else {
+            e = hipMemcpyAsync(d + r0 * row_len, buf, (r1 - r0) * row_len, hipMemcpyHostToDevice, copy);
+        }
         if (e == hipSuccess) e = hipEventRecord(drained[turn], copy);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(copy);
     for (int b = 0; b < 2; ++b) {
         if (drained[b]) (void)hipEventDestroy(drained[b]);
         if (stage[b]) (void)hipHostFree(stage[b]);
+        if (dchunk[b]) (void)hipFree(dchunk[b]);
     }
     if (copy) (void)hipStreamDestroy(copy);
     if (e != hipSuccess) {

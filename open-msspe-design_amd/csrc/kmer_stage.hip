@@ -14,15 +14,17 @@
 // because a segment is covered at most once.
 //
 // Kernels are HBM-bound integer/byte work: instance arrays are laid out segment-major so that
-// extraction writes and the cover step's reads are coalesced; the sort is hipCUB's radix sort.
+// extraction writes and the cover step's reads are coalesced; the sort is rocPRIM's radix sort.
 #include "kmer_stage.hpp"
-
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 namespace msspe {
 
@@ -58,9 +60,44 @@ __device__ __forceinline__ int base2(uint8_t c)
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
 }
 
+// Column `col` of record `rec` as an ASCII letter ('N' for anything that is not A, C, G or T), from the
+// byte matrix or from the packed rows (2-bit bases + validity bit): consecutive columns of a packed row
+// share a word, so the lanes of a wave that read consecutive columns issue one broadcast load each.
+__device__ __forceinline__ uint8_t seq_at(const SeqView &v, size_t rec, size_t col)
+{
+    if (v.ascii) return v.ascii[rec * v.seq_len + col];
+    const size_t bw = (v.seq_len + 31) / 32, rw = bw + (v.seq_len + 63) / 64;
+    const uint64_t *row = v.packed + rec * rw;
+    const bool ok = (row[bw + (col >> 6)] >> (col & 63)) & 1ull;
+    const int code = (int)((row[col >> 5] >> (2 * (col & 31))) & 3ull);
+    return ok ? (uint8_t)"ACGT"[code] : (uint8_t)'N';
+}
+
+// ASCII rows -> packed rows: one thread per output word (32 columns of bases or 64 of validity).
+__global__ void __launch_bounds__(256) k_pack_rows(const uint8_t *ascii, int n_rows, size_t row_len, uint64_t *packed)
+{
+    const size_t bw = (row_len + 31) / 32, rw = bw + (row_len + 63) / 64;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_rows * rw) return;
+    const size_t r = t / rw, w = t % rw;
+    const uint8_t *row = ascii + r * row_len;
+    uint64_t out = 0;
+    if (w < bw) {
+        const size_t c0 = w * 32;
+        for (int q = 0; q < 32 && c0 + q < row_len; ++q) {
+            const int b = base2(row[c0 + q]);
+            out |= (uint64_t)(b >= 0 ? b : 0) << (2 * q);   // columns without a base: bits 00, validity 0
+        }
+    } else {
+        const size_t c0 = (w - bw) * 64;
+        for (int q = 0; q < 64 && c0 + q < row_len; ++q) out |= (uint64_t)(base2(row[c0 + q]) >= 0) << q;
+    }
+    packed[t] = out;
+}
+
 // One thread per (segment, window position).  key = lexicographic-order code of the emitted word
 // (first base in the most significant bits); invalid / duplicate positions get the sentinel.
-__global__ void __launch_bounds__(256) k_extract(const uint8_t *seqs, size_t seq_len, int n_seg,
+__global__ void __launch_bounds__(256) k_extract(const SeqView seqs, size_t seq_len, int n_seg,
                                                  int P, int seg_size, int stride, int W, int k,
                                                  int direction, int per, int wins_per_block,
                                                  uint64_t *key_out, uint32_t *val_out)
@@ -78,7 +115,7 @@ __global__ void __launch_bounds__(256) k_extract(const uint8_t *seqs, size_t seq
         if (seg < n_seg) {
             const long rec = seg / P, part = seg % P;
             const size_t col = (size_t)part * stride + (direction ? seg_size - W : 0) + (e % W);
-            c = seqs[(size_t)rec * seq_len + col];
+            c = seq_at(seqs, (size_t)rec, col);
         }
         win[e] = c;
     }
@@ -469,7 +506,7 @@ __device__ __forceinline__ bool has_word(const uint64_t *set, int n, uint64_t w)
     return lo < n && set[lo] == w;
 }
 
-__global__ void __launch_bounds__(256) k_segment_hits(const uint8_t *seqs, size_t seq_len, int n_seg, int P,
+__global__ void __launch_bounds__(256) k_segment_hits(const SeqView seqs, size_t seq_len, int n_seg, int P,
                                                       int seg_size, int stride, int W, int k,
                                                       const uint64_t *fwd, int n_fwd, const uint64_t *rev,
                                                       int n_rev, uint8_t *hit)
@@ -479,15 +516,14 @@ __global__ void __launch_bounds__(256) k_segment_hits(const uint8_t *seqs, size_
     const int n_waves = gridDim.x * (blockDim.x >> 6);
     const int per = W - k + 1;
     for (int seg = wave; seg < n_seg; seg += n_waves) {
-        const size_t base = (size_t)(seg / P) * seq_len + (size_t)(seg % P) * (size_t)stride;
+        const size_t rec = (size_t)(seg / P), col0 = (size_t)(seg % P) * (size_t)stride;
         bool found = false;
         for (int p = lane; p < per; p += 64) {
             uint64_t wf = 0, wr = 0;
             bool okf = true, okr = true;
-            const uint8_t *head = seqs + base + p;
-            const uint8_t *tail = seqs + base + (size_t)(seg_size - W) + p;
+            const size_t head = col0 + p, tail = col0 + (size_t)(seg_size - W) + p;
             for (int q = 0; q < k; ++q) {
-                const int cf = base2(head[q]), cr = base2(tail[k - 1 - q]);
+                const int cf = base2(seq_at(seqs, rec, head + q)), cr = base2(seq_at(seqs, rec, tail + (k - 1 - q)));
                 okf &= cf >= 0;
                 okr &= cr >= 0;
                 wf |= (uint64_t)(cf & 3) << (2 * q);
@@ -543,7 +579,16 @@ void KmerStage::release()
         }                                                                   \
     } while (0)
 
-int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+hipError_t launch_pack_rows(const uint8_t *d_ascii, int n_rows, size_t row_len, uint64_t *d_packed, hipStream_t stream)
+{
+    const size_t words = (size_t)n_rows * SeqView::row_words(row_len);
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, d_ascii, n_rows,
+                       row_len, d_packed);
+    return hipGetLastError();
+}
+
+int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
                    int direction, uint64_t *words_out, uint32_t *freq_out, int capacity,
                    int *n_out, hipStream_t stream, std::string &err)
 {
@@ -611,15 +656,15 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     KM_TRY(hipGetLastError());
     // 2. inverted index: stable radix sort on the 2k+1 key bits keeps ascending segment order
     size_t tmp_bytes = 0, tmp2 = 0;
-    KM_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b,
-                                              (int)n_inst, 0, 2 * k + 1, stream));
-    KM_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, head, hscan, (int)n_inst, stream));
+    KM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b, n_inst, 0u,
+                                     (unsigned)(2 * k + 1), stream));
+    KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
     if ((rc = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc;
-    KM_TRY(hipcub::DeviceRadixSort::SortPairs(buf_[14], tmp_bytes, key_a, key_b, val_a, val_b,
-                                              (int)n_inst, 0, 2 * k + 1, stream));
+    KM_TRY(rocprim::radix_sort_pairs(buf_[14], tmp_bytes, key_a, key_b, val_a, val_b, n_inst, 0u,
+                                     (unsigned)(2 * k + 1), stream));
     const int g_inst = (int)((n_inst + 255) / 256);
     hipLaunchKernelGGL(k_heads, dim3(g_inst), dim3(256), 0, stream, key_b, n_inst, sentinel, head);
-    KM_TRY(hipcub::DeviceScan::ExclusiveSum(buf_[14], tmp2, head, hscan, (int)n_inst, stream));
+    KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
     uint32_t last_head = 0, last_scan = 0;
     KM_TRY(hipMemcpyAsync(&last_head, head + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
     KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
@@ -710,7 +755,7 @@ int KmerStage::run(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe
     return MSSPE_OK;
 }
 
-int KmerStage::coverage(const uint8_t *d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
+int KmerStage::coverage(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe_kmer_opt &opt,
                         const uint64_t *fwd_words, int n_fwd, const uint64_t *rev_words, int n_rev,
                         uint8_t *hit_out, hipStream_t stream, std::string &err)
 {

@@ -291,7 +291,8 @@ DeviceAlignment::DeviceAlignment(Engine &eng, const std::vector<SequenceRecord> 
         rows[r] = records[r].sequence.data();
         bytes[r] = records[r].sequence.size();
     }
-    const int rc = msspe_device_put_rows(eng.ctx(), rows.data(), bytes.data(), rows_, len_, '-', &dev_);
+    // packed on the device: 2-bit bases + validity bit (3/8 byte per column stay resident)
+    const int rc = msspe_device_put_rows_packed(eng.ctx(), rows.data(), bytes.data(), rows_, len_, &dev_);
     if (rc) eng.fail(rc);
 }
 
@@ -314,7 +315,7 @@ std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const DeviceAlignm
     std::vector<uint64_t> words((size_t)cap);
     std::vector<uint32_t> freq((size_t)cap);
     int n = 0;
-    const int rc = msspe_kmer_candidates_dev(eng.ctx(), aln.device(), aln.rows(), aln.length(), &opt, direction,
+    const int rc = msspe_kmer_candidates_packed_dev(eng.ctx(), aln.device(), aln.rows(), aln.length(), &opt, direction,
                                              words.data(), freq.data(), cap, &n);
     if (rc) eng.fail(rc);
     std::vector<char> buf((size_t)opt.kmer_size + 1);
@@ -583,7 +584,7 @@ std::string coverage_report(Engine &eng, const DeviceAlignment &aln, const std::
     if (P) {
         const auto wf = pack_words(eng, fwd, kmer_size), wr = pack_words(eng, rev, kmer_size);
         msspe_kmer_opt opt{segment_size, overlap_size, window_size, kmer_size, 0, 0};
-        const int rc = msspe_segment_coverage_dev(eng.ctx(), aln.device(), aln.rows(), L, &opt, wf.data(),
+        const int rc = msspe_segment_coverage_packed_dev(eng.ctx(), aln.device(), aln.rows(), L, &opt, wf.data(),
                                                   (int)wf.size(), wr.data(), (int)wr.size(), hit.data());
         if (rc) eng.fail(rc);
     }

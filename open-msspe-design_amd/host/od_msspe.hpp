@@ -132,7 +132,7 @@ public:
     ~DeviceAlignment();
     DeviceAlignment(const DeviceAlignment &) = delete;
     DeviceAlignment &operator=(const DeviceAlignment &) = delete;
-    const uint8_t *device() const { return static_cast<const uint8_t *>(dev_); }
+    const uint64_t *device() const { return static_cast<const uint64_t *>(dev_); }   // packed rows (msspe_device_put_rows_packed)
     int rows() const { return rows_; }
     size_t length() const { return len_; }
 

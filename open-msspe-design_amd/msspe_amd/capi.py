@@ -21,6 +21,8 @@ EXPORTS = [
     "msspe_device_put", "msspe_device_free", "msspe_thal_detail_pairs", "msspe_profile_enable", "msspe_profile_read",
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
+    "msspe_packed_row_words", "msspe_device_put_rows_packed", "msspe_kmer_candidates_packed_dev",
+    "msspe_segment_coverage_packed_dev",
     "msspe_round_fixed_f32", "msspe_g_cut",
 ]
 
@@ -112,9 +114,15 @@ def load_library() -> C.CDLL:
     L.msspe_kmer_candidates.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), C.c_int,
                                         vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.msspe_kmer_candidates_dev.argtypes = L.msspe_kmer_candidates.argtypes
+    L.msspe_kmer_candidates_packed_dev.argtypes = L.msspe_kmer_candidates.argtypes
+    L.msspe_packed_row_words.restype = C.c_size_t
+    L.msspe_packed_row_words.argtypes = [C.c_size_t]
+    L.msspe_device_put_rows_packed.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t,
+                                               C.POINTER(vp)]
     L.msspe_segment_coverage.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), vp, C.c_int, vp, C.c_int,
                                          vp]
     L.msspe_segment_coverage_dev.argtypes = L.msspe_segment_coverage.argtypes
+    L.msspe_segment_coverage_packed_dev.argtypes = L.msspe_segment_coverage.argtypes
     L.msspe_round_g_f32.restype = C.c_float
     L.msspe_round_g_f32.argtypes = [C.c_double]
     L.msspe_round_fixed_f32.restype = C.c_float

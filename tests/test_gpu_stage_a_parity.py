@@ -197,3 +197,70 @@ def test_segment_coverage_matches_a_string_search(eng, m, oracle):
                 want[i, j] = any(w in sf for w in head) or any(oracle.reverse_complement(w) in sr for w in tail)
         np.testing.assert_array_equal(hit, want)
     assert hit.shape == (30, (5000 - 500) // 250 + 1)
+
+
+def test_packed_alignment_equals_the_ascii_path(eng, m, oracle):
+    """msspe_device_put_rows_packed (2-bit bases + validity bit, packed on the device) and the *_packed_dev
+    entry points: the packed words are what a host-side packing gives, stage A's winners and the coverage
+    hits are identical to the byte-matrix path (ragged rows, gaps, N, IUPAC codes, several upload chunks)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(5)
+    base = m.synth.aligned_genomes(650, 30000)
+    base[7, 1000:1040] = np.frombuffer(b"RYKMSWBDHVRYKMSWBDHVRYKMSWBDHVRYKMSWBDHV", dtype=np.uint8)
+    rows = [bytes(r[: 30000 - int(rng.integers(0, 300))]) for r in base]
+    L = 30000
+    arr = np.full((len(rows), L), ord("-"), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        arr[i, : len(r)] = np.frombuffer(r, dtype=np.uint8)
+    ptrs = (C.c_char_p * len(rows))(*rows)
+    lens = (C.c_size_t * len(rows))(*[len(r) for r in rows])
+    dev = C.c_void_p()
+    eng.L.msspe_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    assert eng.L.msspe_device_put_rows_packed(eng.ptr, ptrs, lens, len(rows), L, C.byref(dev)) == 0
+    try:
+        rw = int(eng.L.msspe_packed_row_words(L))
+        bw = (L + 31) // 32
+        assert rw == bw + (L + 63) // 64
+        # the packed image against numpy
+        code = np.full(256, 4, dtype=np.uint8)
+        for q, ch in enumerate(b"ACGT"):
+            code[ch] = q
+        c = code[arr]
+        pad = np.zeros((len(rows), bw * 32 - L), dtype=np.uint8)
+        bases = (np.concatenate([c & 3, pad], 1).reshape(len(rows), bw, 32).astype(np.uint64)
+                 << (2 * np.arange(32, dtype=np.uint64))[None, None, :]).sum(2, dtype=np.uint64)
+        vpad = np.zeros((len(rows), (rw - bw) * 64 - L), dtype=np.uint8)
+        valid = (np.concatenate([(c < 4).astype(np.uint8), vpad], 1).reshape(len(rows), rw - bw, 64).astype(np.uint64)
+                 << np.arange(64, dtype=np.uint64)[None, None, :]).sum(2, dtype=np.uint64)
+        got_words = np.empty((len(rows), rw), dtype=np.uint64)
+        torch.cuda.synchronize()
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(got_words.ctypes.data), dev, ctypes.c_size_t(got_words.nbytes), 2) == 0
+        np.testing.assert_array_equal(got_words[:, :bw], bases)
+        np.testing.assert_array_equal(got_words[:, bw:], valid)
+        # stage A and the coverage report's segment search on the packed form
+        opt = m.KmerOpt(500, 250, 50, 13, 60, 3)
+        words = np.zeros(60, dtype=np.uint64)
+        freqs = np.zeros(60, dtype=np.uint32)
+        winners = {}
+        for d in (0, 1):
+            n_out = C.c_int(0)
+            assert eng.L.msspe_kmer_candidates_packed_dev(eng.ptr, dev, len(rows), L, C.byref(opt), d, words.ctypes.data,
+                                                          freqs.ctypes.data, 60, C.byref(n_out)) == 0
+            want = eng.kmer_candidates(arr, opt, d)
+            got = [m.unpack_oligo(w, 13) for w in words[: n_out.value]]
+            assert got == want[0] and freqs[: n_out.value].tolist() == want[1].tolist() and len(got) == 60
+            winners[d] = words[: n_out.value].copy()
+        P = (L - 500) // 250 + 1
+        hit_p = np.zeros(len(rows) * P, dtype=np.uint8)
+        hit_a = np.zeros(len(rows) * P, dtype=np.uint8)
+        assert eng.L.msspe_segment_coverage_packed_dev(eng.ptr, dev, len(rows), L, C.byref(opt), winners[0].ctypes.data, 60,
+                                                       winners[1].ctypes.data, 60, hit_p.ctypes.data) == 0
+        assert eng.L.msspe_segment_coverage(eng.ptr, arr.ctypes.data, len(rows), L, C.byref(opt), winners[0].ctypes.data, 60,
+                                            winners[1].ctypes.data, 60, hit_a.ctypes.data) == 0
+        np.testing.assert_array_equal(hit_p, hit_a)
+        assert 0 < hit_p.sum() < hit_p.size
+    finally:
+        assert eng.L.msspe_device_free(eng.ptr, dev) == 0
