@@ -67,7 +67,10 @@ constexpr int kRowTEntries = kRowL2 * kRowA;
 constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
 constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
 constexpr int kNoY = 1 << 28;                    // table entries at or above kNoY / 2 carry this offset: no cell-side term
-constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
+#ifndef MSSPE_ROW_SEG
+#define MSSPE_ROW_SEG 256
+#endif
+constexpr int kSegGroups = MSSPE_ROW_SEG;        // column groups (of 64) per work item
 // slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
 //             bits 14..0   h + kHBias
 constexpr int kEmptyRowW = ((15 * kRowA) << 17) | kHBias;  // jj = 15: right of every cell

@@ -256,6 +256,15 @@ class Engine:
             raise err
         return edges[:count.value], int(count.value)
 
+    def cross_dimer_edges_dev(self, d_pool: int, n: int, k: int, chem: Chem, threshold: float,
+                              rows: tuple[int, int], cols: tuple[int, int], d_edges: int, capacity: int,
+                              d_count: int, d_row_conflicts: int = 0):
+        """Device-pointer edge list of a block (16-byte records a:u32, b:u32, dg:f64; *d_count may exceed
+        the capacity = truncated); asynchronous."""
+        self._check(self.L.msspe_cross_dimer_edges_dev(
+            self.ptr, C.c_void_p(d_pool), n, k, C.byref(chem), C.c_float(threshold), rows[0], rows[1], cols[0],
+            cols[1], C.c_void_p(d_row_conflicts), C.c_void_p(d_edges), capacity, C.c_void_p(d_count)))
+
     def cross_dimer_dev(self, d_pool: int, n: int, k: int, chem: Chem, threshold: float,
                         rows: tuple[int, int], cols: tuple[int, int], d_row_conflicts: int = 0,
                         d_bitmap: int = 0, d_dg: int = 0, d_tm: int = 0):
