@@ -44,6 +44,12 @@
 #ifndef MSSPE_KO
 #define MSSPE_KO 0
 #endif
+#ifndef MSSPE_ROW_ARGS_LDS
+#define MSSPE_ROW_ARGS_LDS 0
+#endif
+#ifndef MSSPE_ROW_WMAX_BALLOT
+#define MSSPE_ROW_WMAX_BALLOT 1
+#endif
 #ifndef MSSPE_ROW_SATSUB
 #define MSSPE_ROW_SATSUB 0
 #endif
@@ -93,6 +99,10 @@ struct SharedRow {
     unsigned short path[kPathMax][kRowThreads];
     unsigned next_group;
     int item;
+    // The kernel's arguments (experiment MSSPE_ROW_ARGS_LDS: read from here at the point of use they have no
+    // live range across the DP; measured: scratch write-back 5.1 -> 0.9 GB per launch, but the launch takes
+    // 99 ms instead of 63, the values arriving in vector registers; left off)
+    IntArgs args;
 };
 
 struct KParts {
@@ -127,6 +137,23 @@ __device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
     return (h << 14) | (po << 8) | (p.ii << 4) | p.jj;
 }
 __device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
+
+// Largest value over the lanes of the wave for 0 <= v < 256: bisection on ballots.  (The shuffle-based
+// wave_max of pair_core.hpp keeps six lane-address vectors alive across the whole DP -- registers this
+// kernel does not have.)
+__device__ __forceinline__ int wave_max_u8(int v)
+{
+#if !MSSPE_ROW_WMAX_BALLOT
+    return wave_max(v);
+#endif
+    int lo = 0;   // the answer is in [lo, lo + 2 * span)
+#pragma unroll
+    for (int span = 128; span > 0; span >>= 1) {
+        const bool above = v >= lo + span;
+        lo += __builtin_amdgcn_ballot_w64(above) ? span : 0;
+    }
+    return lo;
+}
 
 struct RCell {
     unsigned C;     // per-cell minuend of the address subtraction
@@ -400,7 +427,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     }
     {
         int prevCore = 0;
-        const int maxP = wave_max(P);
+        const int maxP = wave_max_u8(P);
         for (int step_ = 0; step_ < maxP; ++step_) {
             const int step = __builtin_amdgcn_readfirstlane(step_);
             const int e = P - 1 - step;
@@ -456,17 +483,22 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     const int lane = threadIdx.x & 63;
     SeqPair q;
     unsigned rowmask;
-    int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
+    // (values read from the LDS copy of the arguments are vector registers: what steers control flow is
+    // made a scalar again, or every loop over it becomes a divergent one)
+    const int k = __builtin_amdgcn_readfirstlane(a.f.k);
+    int n_cells = setup_pair(pa, pb, k, q, rowmask);
     q.s1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.s1);   // the block's row primer: a scalar
-    const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
+    q.len = k;
+    q.lenmask = (unsigned)__builtin_amdgcn_readfirstlane((int)q.lenmask);
+    const bool sym = self_complementary(pa, k) && self_complementary(pb, k);
     bool spill = inside & ((n_cells > NS) | sym);
     unsigned flag = 0u;
     if (!inside | spill) n_cells = 0;
-    int nmax = wave_max(n_cells);
+    int nmax = wave_max_u8(n_cells);
     // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes far above
     // the rest (mixed compositions at bin boundaries) are cheaper in a sorted list stage.
     for (int round = 0; round < 6; ++round) {
-        const int next = wave_max(n_cells < nmax ? n_cells : 0);
+        const int next = wave_max_u8(n_cells < nmax ? n_cells : 0);
         const int m = __popcll(__ballot(n_cells == nmax));
         if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
         if (n_cells == nmax) {
@@ -486,7 +518,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
         n_slots = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            w4[b] = wave_max(n_cells > 0 ? c2[b] : 0);
+            w4[b] = wave_max_u8(n_cells > 0 ? c2[b] : 0);
             n_slots += w4[b] * __popc(spaced_mask(q.s1, 3 - b, lenmask));   // rows whose cells have base b on oligo 2
         }
         if (n_slots <= NS) break;
@@ -504,7 +536,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
             spill = true;
             n_cells = 0;
         }
-        nmax = wave_max(n_cells);
+        nmax = wave_max_u8(n_cells);
     }
     if (nmax == 0) {   // wave-uniform: nothing to compute
         if (spill) {
@@ -627,6 +659,7 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
     }
     for (int e = threadIdx.x; e < 100; e += kRowThreads)
         sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
+    if (threadIdx.x == 0) sh.args = a;
     const int lane = threadIdx.x & 63;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
     const int n_seg = (ncolg + kSegGroups - 1) / kSegGroups;
@@ -662,7 +695,11 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
             const bool inside = cq < a.f.col1;
             const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
             const int col = (int)a.f.perm[inside ? cq : a.f.col0];
+#if MSSPE_ROW_ARGS_LDS
+            wave_pairs_row<NS>(sh, sh.args, row, col, pa, pb, inside);
+#else
             wave_pairs_row<NS>(sh, a, row, col, pa, pb, inside);
+#endif
         }
         __syncthreads();   // every wave is done with the table (and with sh.item) before the next item
     }

@@ -1,15 +1,19 @@
 #!/bin/bash
 # Collects the round's profile artefacts on the GPU box into gpurun_out/profiles_raw/ (copy the
-# summaries into profiles/ afterwards with tools/summarise_profiles.py).  Every rocprofv3 run
+# summaries into profiles/ afterwards with tools/summarise_profiles.py <round>).  Every rocprofv3 run
 # starts the python interpreter itself (no env/bash wrapper), counters in their own passes.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_raw
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o bench -- python3 bench.py --steps 2 --warmup 1 > $OUT/bench_stdout.log 2>&1 || exit 1
+echo "bench done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc1 -- python3 tools/perf_probe.py 16384 > $OUT/pmc1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- python3 tools/perf_probe.py 16384 > $OUT/pmc2.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/perf_probe.py 16384 > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/perf_probe.py 16384 > $OUT/pmc_write.log 2>&1 || exit 1
+echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_a_stats -o stagea -- python3 tools/perf_stage_a.py 10000 30000 > $OUT/stage_a_stdout.log 2>&1 || exit 1
+echo "stage a done"
+timeout -k 10 700 tools/valu_peak > $OUT/valu_peak.jsonl 2>&1
 echo done

@@ -14,8 +14,8 @@ OUT = ROOT / "profiles"
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 kLaunchChecks = 134217728.0            # 2^27 pairs: one full launch
 kProbeChecks = 3.0 * 16384.0 * 16384.0   # tools/perf_probe.py 16384 = three passes over the pool
-KERNEL = "k_pairs_int"
-KERNEL_MATCH = "k_pairs_int<"   # the matrix-mode instantiation (the list mode is k_pairs_int_list)
+KERNEL = "k_pairs_row"
+KERNEL_MATCH = "k_pairs_row<"   # the row-specialised first stage (thal_pairs_row.hip)
 
 
 def pmc(sub):
@@ -61,8 +61,12 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write("## derived\n")
     f.write(f"VALU instructions per check (per lane)      {c1['SQ_INSTS_VALU'] / waves:.0f}\n")
     f.write(f"SALU / LDS / branch per wave-batch          {c1['SQ_INSTS_SALU'] / waves:.0f} / {c1['SQ_INSTS_LDS'] / waves:.0f} / {c1['SQ_INSTS_BRANCH'] / waves:.0f}\n")
-    f.write(f"VALU busy share of all SIMD issue slots     {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}"
-            f"   (one wave instruction per SIMD per 4 cycles = 1.0; the clock is GRBM_GUI_ACTIVE / 8 / time, good to a few %)\n")
+    per_simd_cycles = c2['GRBM_GUI_ACTIVE'] / 8.0
+    f.write(f"cycles per VALU instruction per SIMD        {per_simd_cycles / (c1['SQ_INSTS_VALU'] / 1024.0):.3f}"
+            f"   (measured issue limits, profiles/{ROUND}_valu_peak.txt: 2.4 for add/sub/and/or/lshr/mov, 4.3 for the rest, "
+            f"v_cmp 5.5 at three waves per SIMD)\n")
+    f.write(f"wave cycles: active / issue-stalled / waiting   {c2['SQ_ACTIVE_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / "
+            f"{c1['SQ_WAIT_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / {c1['SQ_WAIT_ANY'] / c1['SQ_WAVE_CYCLES']:.3f}\n")
     f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
@@ -72,18 +76,44 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
-    "note": "scaled to one full launch of 2^27 ordered pairs; traffic = write-back of the spilled registers of the "
-            "three-wave kernel shape (scratch), the 64-byte atomics that set conflict bits (0.5 % of pairs), the list of "
-            "pairs handed to the later stages (about 7 %, 8 B each) and the table loads of the persistent blocks; "
-            "algorithmic bytes per launch are about 21 MB"}, indent=1))
+    "note": "scaled to one full launch of 2^27 ordered pairs; traffic = the 64-byte atomics that set conflict bits "
+            "(0.5 % of pairs), the list of pairs handed to the later stages (about 7 %, 8 B each), the per-pair register "
+            "spills of the three-wave shape (none inside the cell loop) and the per-row table builds; algorithmic bytes "
+            "per launch are about 21 MB"}, indent=1))
 (OUT / "pmc_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "source": f"profiles/{ROUND}_pmc_{KERNEL}.txt",
     "valu_instructions_per_check": c1["SQ_INSTS_VALU"] / waves,
     "salu_instructions_per_wave_batch": c1["SQ_INSTS_SALU"] / waves,
     "lds_instructions_per_wave_batch": c1["SQ_INSTS_LDS"] / waves,
-    "valu_busy_fraction": min(1.0, c2["SQ_ACTIVE_INST_VALU"] / simd_quads),
-    "valu_busy_counter_ratio": c2["SQ_ACTIVE_INST_VALU"] / simd_quads,
-    "int32_valu_peak_tops": 256 * 4 * 16 * clock_ghz / 1e3,
+    "cycles_per_valu_instruction_per_simd": (c2["GRBM_GUI_ACTIVE"] / 8.0) / (c1["SQ_INSTS_VALU"] / 1024.0),
+    "measured_issue_limit_cycles": {"add/sub/and/or/lshr/mov": 2.4, "other VALU": 4.3, "v_cmp at 3 waves/SIMD": 5.5,
+                                    "source": f"profiles/{ROUND}_valu_peak.txt"},
+    "wave_cycle_shares": {"active": c2["SQ_ACTIVE_INST_ANY"] / c1["SQ_WAVE_CYCLES"],
+                          "issue_stalled": c1["SQ_WAIT_INST_ANY"] / c1["SQ_WAVE_CYCLES"],
+                          "waiting": c1["SQ_WAIT_ANY"] / c1["SQ_WAVE_CYCLES"]},
+    "lds_bank_conflict_share": c2["SQ_LDS_BANK_CONFLICT"] / c2["SQ_LDS_IDX_ACTIVE"],
     "achieved_int32_tops": c1["SQ_INSTS_VALU"] * 64 / (ms1 * 1e-3) / 1e12,
     "clock_ghz": clock_ghz}, indent=1))
+# VALU issue-rate microbenchmark -> readable table
+vp = RAW / "valu_peak.jsonl"
+if vp.exists():
+    rows = collections.OrderedDict()
+    head = ""
+    for l in open(vp):
+        try:
+            d = json.loads(l)
+        except Exception:
+            continue
+        if "op" not in d:
+            head = json.dumps(d)
+            continue
+        rows.setdefault(d["op"], {})[d["waves_per_simd"]] = d["cycles_per_valu_per_simd"]
+    shutil.copy(vp, OUT / f"{ROUND}_valu_peak.jsonl")
+    with open(OUT / f"{ROUND}_valu_peak.txt", "w") as f:
+        f.write("# tools/valu_peak (tools/valu_peak.hip): cycles per wave64 VALU instruction per SIMD, independent chains,\n"
+                "# every CU busy, 1..4 waves per SIMD; cycles = launch wall time x in-kernel clock (s_memtime / s_memrealtime)\n"
+                f"# {head}\n")
+        f.write(f"{'op':30s} {'w=1':>6s} {'w=2':>6s} {'w=3':>6s} {'w=4':>6s}\n")
+        for k, v in rows.items():
+            f.write(f"{k:30s} " + " ".join(f"{v.get(w, float('nan')):6.2f}" for w in (1, 2, 3, 4)) + "\n")
 print(open(OUT / f"{ROUND}_pmc_{KERNEL}.txt").read())

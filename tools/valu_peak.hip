@@ -161,16 +161,6 @@ DEF_KERNEL(k_cndmask_b32_e32_vcc, B, REP8)
 #define REP4(I) I(0) I(1) I(2) I(3)
 DEF_KERNEL(k_cmp_then_cndmask_e64, B, REP4)
 #undef B
-// the scan's visit_finish_far as written: add3, cmp lt, cmp eq, min, cndmask (5 VALU + 2 SALU per visit)
-#define B(n)                                                                                             \
-    asm volatile("v_add3_u32 %0, %0, %1, %2\n\tv_cmp_lt_i32_e64 s[40:41], %0, %1\n\t"                    \
-                 "v_cmp_eq_u32_e64 s[42:43], %0, %1\n\tv_min_i32 %0, %0, %1\n\t"                         \
-                 "v_cndmask_b32_e64 %0, %0, %2, s[40:41]\n\ts_andn2_b64 s[44:45], s[44:45], s[40:41]\n\t" \
-                 "s_or_b64 s[44:45], s[44:45], s[42:43]\n\tv_and_b32 %0, %0, %1"                         \
-                 : "+v"(r##n) : "v"(x), "v"(y) : "s40", "s41", "s42", "s43", "s44", "s45");
-// 6 VALU per statement: count 8 statements = 48 VALU + 16 SALU
-DEF_KERNEL(k_finish_mix_6valu_2salu, B, REP8)
-#undef B
 // ---- lane crossing, LDS
 #define B(n) asm volatile("v_readlane_b32 s40, %0, 3" : : "v"(r##n) : "s40");
 DEF_KERNEL(k_readlane_b32, B, REP8)
@@ -263,7 +253,6 @@ int main()
         OP(k_mul_u32_u24), OP(k_mul_lo_u32), OP(k_sub_u32_sdwa), OP(k_ffbl_b32), OP(k_cmp_lt_i32_e64), OP(k_cmp_lt_i32_e32),
         OP(k_cmp_eq_u32_sdwa), OP(k_cndmask_b32_e64_sgpr), OP(k_cndmask_b32_e32_vcc),
         {"k_cmp_then_cndmask_e64", k_cmp_then_cndmask_e64, kUnroll},
-        {"k_finish_mix_6valu_2salu", k_finish_mix_6valu_2salu, 6 * 8 * (kUnroll / 8)},
         OP(k_readlane_b32), OP(k_mov_b32_dpp), OP(k_fma_f32), OP(k_add_f32), OP(k_pk_fma_f32), OP(k_fma_f64), OP(k_add_f64),
         OP(k_mul_f64), OP(k_cvt_f64_i32)};
     for (const OpDesc &op : ops) run_op(op, n_cu, d_sink, d_cycles);
