@@ -105,6 +105,20 @@ struct RBest {
     int G, W, G2;
 };
 
+// Largest value over the lanes of the wave for 0 <= v < 256: bisection on ballots.  (The shuffle-based
+// wave_max of pair_core.hpp keeps six lane-address vectors alive across the whole DP -- registers this
+// kernel does not have.)
+__device__ __forceinline__ int wave_max_u8(int v)
+{
+    int lo = 0;   // the answer is in [lo, lo + 2 * span)
+#pragma unroll
+    for (int span = 128; span > 0; span >>= 1) {
+        const bool above = v >= lo + span;
+        lo += __builtin_amdgcn_ballot_w64(above) ? span : 0;
+    }
+    return lo;
+}
+
 // Smallest value over the lanes of the wave for 0 <= v < 64: bisection on ballots (no LDS traffic).
 __device__ __forceinline__ int wave_min_64(int v)
 {

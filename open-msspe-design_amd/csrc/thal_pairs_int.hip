@@ -371,7 +371,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         H = 0;
         {
             int prevW = 0;
-            const int maxP = wave_max(P);
+            const int maxP = wave_max_u8(P);
             for (int step_ = 0; step_ < maxP; ++step_) {
                 const int step = __builtin_amdgcn_readfirstlane(step_);
                 const int e = P - 1 - step;
@@ -473,12 +473,12 @@ __device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, in
     bool spill = inside & (pass_on | (n_cells > NS) | sym);
     unsigned flag = pass_on ? pass_flag : 0u;
     if (!inside | spill) n_cells = 0;
-    int nmax = wave_max(n_cells);
+    int nmax = wave_max_u8(n_cells);
     // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes
     // far above the rest (mixed compositions at bin boundaries) are cheaper in a sorted list
     // stage than as a drag on 64 lanes.
     for (int round = 0; round < 6; ++round) {
-        const int next = wave_max(n_cells < nmax ? n_cells : 0);
+        const int next = wave_max_u8(n_cells < nmax ? n_cells : 0);
         const int m = __popcll(__ballot(n_cells == nmax));
         if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
         if (n_cells == nmax) {

@@ -47,9 +47,6 @@
 #ifndef MSSPE_ROW_ARGS_LDS
 #define MSSPE_ROW_ARGS_LDS 0
 #endif
-#ifndef MSSPE_ROW_WMAX_BALLOT
-#define MSSPE_ROW_WMAX_BALLOT 1
-#endif
 #ifndef MSSPE_ROW_SATSUB
 #define MSSPE_ROW_SATSUB 0
 #endif
@@ -137,23 +134,6 @@ __device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
     return (h << 14) | (po << 8) | (p.ii << 4) | p.jj;
 }
 __device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
-
-// Largest value over the lanes of the wave for 0 <= v < 256: bisection on ballots.  (The shuffle-based
-// wave_max of pair_core.hpp keeps six lane-address vectors alive across the whole DP -- registers this
-// kernel does not have.)
-__device__ __forceinline__ int wave_max_u8(int v)
-{
-#if !MSSPE_ROW_WMAX_BALLOT
-    return wave_max(v);
-#endif
-    int lo = 0;   // the answer is in [lo, lo + 2 * span)
-#pragma unroll
-    for (int span = 128; span > 0; span >>= 1) {
-        const bool above = v >= lo + span;
-        lo += __builtin_amdgcn_ballot_w64(above) ? span : 0;
-    }
-    return lo;
-}
 
 struct RCell {
     unsigned C;     // per-cell minuend of the address subtraction
