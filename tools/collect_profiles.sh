@@ -15,5 +15,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tool
 echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_a_stats -o stagea -- python3 tools/perf_stage_a.py 10000 30000 > $OUT/stage_a_stdout.log 2>&1 || exit 1
 echo "stage a done"
-timeout -k 10 700 tools/valu_peak > $OUT/valu_peak.jsonl 2>&1
+timeout -k 10 120 tools/valu_peak > $OUT/valu_peak.jsonl 2>&1; echo "valu_peak done"
 echo done
