@@ -570,6 +570,17 @@ void KmerStage::release()
     }
 }
 
+// the greedy loop's graph objects, released on every way out of KmerStage::run
+struct GraphGuard {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~GraphGuard()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
+
 #define KM_TRY(expr)                                                        \
     do {                                                                    \
         hipError_t e__ = (expr);                                            \
@@ -707,8 +718,9 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration:
     // 29 -> 27 ms per direction at 10,000 genomes)
     constexpr int kBatch = 32;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    GraphGuard gg;
+    hipGraph_t &graph = gg.graph;
+    hipGraphExec_t &exec = gg.exec;
     bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
     if (use_graph) {
         // capture on a private stream so that the caller's stream may be of any kind
@@ -736,8 +748,6 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
     }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
     const int n_win = h.n_win;
     if (h.maxf > 1 && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
         // the caller's buffers ended the loop, not the reference's rules
