@@ -71,6 +71,29 @@ def pool_size_for(n_gpus: int) -> int:
     return int(round(n / q)) * q
 
 
+def ntthal_live(pool_ascii: np.ndarray, pairs: int = 100000):
+    """if the GPU box has Primer3's `ntthal` on $PATH, time the real thing (one
+    process, one core, its -i stdin mode as od-msspe/src/delta_g.rs:93-145 drives it) on the first `pairs`
+    ordered pairs of the pool.  None when there is no ntthal (the case on every box seen so far)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("ntthal")
+    if exe is None:
+        return None
+    n = pool_ascii.shape[0]
+    rows = max(1, min(n, pairs // n))
+    prim = [bytes(r).decode() for r in pool_ascii]
+    stdin = "\n".join(f"{prim[i]},{b}" for i in range(rows) for b in prim)
+    t0 = time.perf_counter()
+    res = subprocess.run([exe, "-a", "ANY", "-mv", "50.00", "-dv", "3.00", "-n", "0.00", "-d", "250.00", "-t", "25.00",
+                          "-i"], input=stdin, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    if res.returncode != 0:
+        return {"error": res.stderr[-200:]}
+    return {"value": rows * n / dt, "unit": "checks/s", "cores": 1, "kind": "reference",
+            "sample": f"{rows * n} ordered pairs through {exe} -i, {dt:.1f} s"}
+
+
 def cpu_baseline(pool_ascii: np.ndarray, seconds: float, gpu_bitmap_rows: np.ndarray | None):
     """The CPU restatement of the reference path (the oracle), timed on this box's host cores on a
     bounded sample of the same workload: the first R rows x all columns.  Checker only: its
@@ -93,7 +116,9 @@ def cpu_baseline(pool_ascii: np.ndarray, seconds: float, gpu_bitmap_rows: np.nda
     if gpu_bitmap_rows is not None:
         got = np.unpackbits(gpu_bitmap_rows[:rows].view(np.uint8), axis=1, bitorder="little")[:, :n]
         agree = bool(np.array_equal(got.astype(bool), cf.astype(bool)))
-    return {"value": rows * n / dt, "unit": "checks/s", "cores": cores, "kind": "port",
+    live = ntthal_live(pool_ascii)
+    return {"ntthal_live": live,
+            "value": rows * n / dt, "unit": "checks/s", "cores": cores, "kind": "port",
             "sample": f"rows 0..{rows - 1} x all {n} columns of the same pool ({rows * n} checks, "
                       f"{dt:.1f} s, OpenMP over rows); CPU restatement of the reference path, the "
                       f"reference binary (Rust + external ntthal) is not buildable offline",

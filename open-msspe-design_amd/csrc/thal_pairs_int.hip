@@ -562,6 +562,8 @@ __global__ void __launch_bounds__(THREADS) k_pairs_int(IntArgs a)
         if (lane == 0) item = atomicAdd(a.work_counter, 1u);
         item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= n_items) break;   // wave-uniform
+        // (the fetch above relies on the whole wave arriving here together: wave_pairs returns only through
+        // wave-uniform branches -- keep it that way, or a lane runs ahead of the readfirstlane)
         const int row = a.f.row0 + (int)(item / (unsigned)ncolg), cg = (int)(item % (unsigned)ncolg);
         const int cq = a.f.col0 + cg * 64 + lane;
         const bool inside = cq < a.f.col1;

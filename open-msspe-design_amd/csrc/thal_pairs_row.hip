@@ -671,6 +671,8 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
             if (lane == 0) grp = atomicAdd(&sh.next_group, 1u);
             grp = g_lo + (unsigned)__builtin_amdgcn_readfirstlane((int)grp);
             if (grp >= g_hi) break;   // wave-uniform
+            // (the fetch relies on the whole wave arriving here together: wave_pairs_row returns only through
+            // wave-uniform branches -- keep it that way, or a lane runs ahead of the readfirstlane)
             const int cq = a.f.col0 + (int)grp * 64 + lane;
             const bool inside = cq < a.f.col1;
             const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
