@@ -81,7 +81,9 @@ const char *msspe_version(void);
  *   "wave_kernel"    "0" | "1"    one-wave-per-pair f64 kernel in the chain (1)
  *   "list_cap_log2"  "0" | "20".."30"   fixed hand-over list size (0: sized by the call)
  *   "split_lanes"    "0" | "2" | "4" | "8"
- *   "stage_a_graph"  "0" | "1"    hipGraph replay of stage A's greedy loop (1) */
+ *   "stage_a_graph"  "0" | "1"    hipGraph replay of stage A's greedy loop (1)
+ *   "stage_a_candidates" "0" | "1"  greedy loop over the list of words near the maximum (1), or over all the
+ *                                 words on every iteration (0); the winners are the same */
 int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value);
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
 int msspe_reset_stream(msspe_ctx *ctx);

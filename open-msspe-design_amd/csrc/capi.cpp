@@ -347,6 +347,9 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "stage_a_graph") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->kmer.set_use_graph(num != 0);
+    } else if (k == "stage_a_candidates") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->kmer.set_narrow_loop(num != 0);
     } else {
         return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: unknown option '" + k + "'");
     }

@@ -22,6 +22,8 @@
 #include <cstring>
 #include <vector>
 
+#include <cstddef>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
@@ -44,7 +46,15 @@ struct Status {
     unsigned n_long;   // tied words with a long posting list (kept at the back of `tied`)
     unsigned ticket;   // last-block detection
     unsigned long long best;   // winner_key() maximum over the tied words
+    // candidate-list loop (k_select / k_cover<true>): every word whose live count is >= theta is in cand[]
+    int theta;
+    unsigned n_cand;
+    int need_rebuild;  // 1: the candidates' maximum fell below theta; the rest of the batch is a no-op
+    unsigned it1;      // stamp of the iteration in flight (n_win + 1)
+    int last_max;      // the maximum the last k_max_count saw (the host's capacity check)
+    unsigned long long best2[2];   // `best` of the candidate-list loop, alternating with the iteration
 };
+static_assert(sizeof(Status) <= 128, "the winners' arrays start 128 bytes into the status buffer");
 
 // Segment ids are genome-major (seg = genome * P + partition: the order the reference walks
 // them in), but a winner's postings are mostly one partition of many genomes.  The per-segment
@@ -204,6 +214,7 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
 constexpr unsigned kLongList = 512;
 constexpr int kTieUnroll = 4;        // 1024-posting chunks whose loads k_tie_long keeps in flight   // posting lists above this get a whole block in k_tie_long
 
+template <bool kRebuild>
 __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
 {
     __shared__ int part[4];
@@ -231,6 +242,17 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
             // left, when the best word is in one segment only, or after max_iterations winners
             const int mf = atomicMax(&st->maxf, 0);
             if (mf <= 1 || st->n_win >= st->max_iter || st->stop_next) st->stop = 1;
+            st->last_max = mf;
+            if (kRebuild) {
+                // head of a batch of the candidate-list loop: counts only fall, so until the maximum drops
+                // below theta the winner and everything tied with it are among the words collected now
+                st->theta = max(2, mf / 2);
+                st->n_cand = 0;
+                st->need_rebuild = 0;
+                st->maxf = 0;
+                st->best2[0] = 0;
+                st->best2[1] = 0;
+            }
             st->n_tied = 0;
             st->n_long = 0;
             st->ticket = 0;
@@ -264,6 +286,23 @@ __global__ void __launch_bounds__(256) k_collect_tied(const int32_t *count, int 
     }
 }
 
+// Words with a live count of at least theta, in any order (wave-aggregated append).
+__global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int M, Status *st, uint32_t *cand)
+{
+    if (st->stop) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool hit = i < M && count[i] >= st->theta;
+    const unsigned long long mh = __ballot(hit);
+    if (mh) {
+        const int first = __ffsll((long long)mh) - 1;
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(&st->n_cand, (unsigned)__popcll(mh));
+        base = __shfl(base, first);
+        if (hit) cand[base + (unsigned)__popcll(mh & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    }
+}
+
 // winner = highest score, then smallest word (= smallest id: ids follow the sorted key order).
 // Scores are positive f32, so their bit patterns order like the values.
 __device__ __forceinline__ unsigned long long winner_key(float score, uint32_t kid)
@@ -275,6 +314,35 @@ __device__ __forceinline__ unsigned long long winner_key(float score, uint32_t k
 // covered segments, and on the first sight of each partition add 1 / (coverage + 1) in f32 (the
 // order of the additions is the reference's).  One wave per tied word; `seen` is a per-wave bitmap
 // in LDS.
+__device__ __forceinline__ float tie_score_wave(uint32_t kid, unsigned *seen, int words, int lane,
+                                                const uint32_t *post_off, const uint32_t *post,
+                                                const uint8_t *ignored, const uint32_t *coverage, int P, int G)
+{
+    for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
+    const uint32_t b = post_off[kid], e = post_off[kid + 1];
+    float acc = 0.0f;
+    for (uint32_t base = b; base < e; base += 64) {
+        const uint32_t i = base + lane;
+        bool fresh = false;
+        int part = -1;
+        if (i < e) {
+            const uint32_t seg = post[i];
+            part = (int)(seg % (uint32_t)P);
+            fresh = !ignored[(uint32_t)part * (uint32_t)G + seg / (uint32_t)P] &&
+                    !((seen[part >> 5] >> (part & 31)) & 1u);
+        }
+        unsigned long long m = __ballot(fresh);
+        while (m) {   // wave-uniform: distinct new partitions in ascending posting order
+            const int l = __ffsll((long long)m) - 1;
+            const int pl = __shfl(part, l);
+            m &= ~__ballot(part == pl);
+            if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+            acc += 1.0f / ((float)coverage[pl] + 1.0f);
+        }
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status *st,
                                                     const uint32_t *post_off, const uint32_t *post,
                                                     const uint8_t *ignored, const uint32_t *coverage,
@@ -292,38 +360,68 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
     }
     unsigned long long best = 0;
     for (unsigned tix = blockIdx.x * 4 + wave; tix < n; tix += gridDim.x * 4) {
-        for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
         const uint32_t kid = tied[tix];
-        const uint32_t b = post_off[kid], e = post_off[kid + 1];
-        float acc = 0.0f;
-        for (uint32_t base = b; base < e; base += 64) {
-            const uint32_t i = base + lane;
-            bool fresh = false;
-            int part = -1;
-            if (i < e) {
-                const uint32_t seg = post[i];
-                part = (int)(seg % (uint32_t)P);
-                fresh = !ignored[(uint32_t)part * (uint32_t)G + seg / (uint32_t)P] &&
-                        !((seen[part >> 5] >> (part & 31)) & 1u);
-            }
-            unsigned long long m = __ballot(fresh);
-            while (m) {   // wave-uniform: distinct new partitions in ascending posting order
-                const int l = __ffsll((long long)m) - 1;
-                const int pl = __shfl(part, l);
-                m &= ~__ballot(part == pl);
-                if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
-                acc += 1.0f / ((float)coverage[pl] + 1.0f);
-            }
-        }
+        const float acc = tie_score_wave(kid, seen, words, lane, post_off, post, ignored, coverage, P, G);
         const unsigned long long key = winner_key(acc, kid);
         best = key > best ? key : best;
     }
     if (lane == 0 && best) atomicMax(&st->best, best);
 }
 
-// The same walk for a long posting list, one 1024-thread block per word: the block loads and
+// The same walk for a long posting list, by a whole 1024-thread block: the block loads and
 // filters 1024 postings at a time; only chunks that hold a not-yet-seen partition (normally just
 // the first) take the ordered path, where the 16 waves resolve their candidates in turn.
+// Every thread of the block calls it; the score is in *acc_s afterwards.
+__device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, float *acc_s, int words,
+                                                const uint32_t *post_off, const uint32_t *post,
+                                                const uint8_t *ignored, const uint32_t *coverage, int P, int G)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int wd = threadIdx.x; wd < words; wd += 1024) seen[wd] = 0u;
+    if (threadIdx.x == 0) *acc_s = 0.0f;
+    const uint32_t b = post_off[kid], e = post_off[kid + 1];
+    __syncthreads();
+    for (uint32_t base = b; base < e; base += 1024 * kTieUnroll) {
+        // kTieUnroll chunks of (post -> ignored) dependent loads in flight at once
+        uint32_t seg[kTieUnroll];
+        bool live[kTieUnroll];
+#pragma unroll
+        for (int u = 0; u < kTieUnroll; ++u) {
+            const uint32_t i = base + u * 1024 + threadIdx.x;
+            seg[u] = i < e ? post[i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < kTieUnroll; ++u)
+            live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
+#pragma unroll
+        for (int u = 0; u < kTieUnroll; ++u) {
+            const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int ps = live[u] ? part : 0;   // in-bounds bitmap index for idle lanes
+            bool fresh = live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u);
+            if (__syncthreads_or(fresh)) {
+                for (int w = 0; w < 16; ++w) {
+                    if (wave == w) {
+                        // partitions taken by the earlier waves of this chunk are visible now
+                        if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
+                        unsigned long long m = __ballot(fresh);
+                        float acc = *acc_s;
+                        while (m) {
+                            const int l = __ffsll((long long)m) - 1;
+                            const int pl = __shfl(part, l);
+                            m &= ~__ballot(part == pl);
+                            if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+                            acc += 1.0f / ((float)coverage[pl] + 1.0f);
+                        }
+                        if (lane == 0) *acc_s = acc;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, Status *st,
                                                    const uint32_t *post_off, const uint32_t *post,
                                                    const uint8_t *ignored, const uint32_t *coverage,
@@ -333,7 +431,6 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
     __shared__ float acc_s;
     if (st->stop) return;
     unsigned *seen = (unsigned *)smem;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int words = (P + 31) / 32;
     const unsigned n = st->n_long;
     if (n + st->n_tied == 1) {   // a single candidate wins whatever its score
@@ -342,51 +439,138 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
         return;
     }
     for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
-        for (int wd = threadIdx.x; wd < words; wd += blockDim.x) seen[wd] = 0u;
-        if (threadIdx.x == 0) acc_s = 0.0f;
         const uint32_t kid = tied[(unsigned)M - 1u - j];
-        const uint32_t b = post_off[kid], e = post_off[kid + 1];
+        tie_score_block(kid, seen, &acc_s, words, post_off, post, ignored, coverage, P, G);
+        if (threadIdx.x == 0) atomicMax(&st->best, winner_key(acc_s, kid));
         __syncthreads();
-        for (uint32_t base = b; base < e; base += 1024 * kTieUnroll) {
-            // kTieUnroll chunks of (post -> ignored) dependent loads in flight at once
-            uint32_t seg[kTieUnroll];
-            bool live[kTieUnroll];
+    }
+}
+
+// ---- candidate-list loop -------------------------------------------------------------------------------
+// One iteration = k_select -> k_cover<true>.  A batch starts with k_max_count<true> + k_collect_cand, which
+// gather the words whose live count is at least theta = max / 2 (a few thousand, against millions of words).
+// Counts only fall, so while the candidates' maximum stays >= theta it is the global maximum and every word
+// tied with it is a candidate: k_select finds the maximum and the tied words by reading the candidates only,
+// every block for itself (no grid-wide step), scores its share of them and posts winner_key() maxima.
+// When the maximum falls below theta the rest of the batch is a no-op and the next batch starts from a
+// fresh list.  The decisions are those of the five-launch iteration: same maximum, same tied set, same
+// scores, same winner.
+constexpr unsigned kCandCap = 32768;   // longer lists go the five-launch way: every block reads all of it
+constexpr int kSelectGrid = 128;
+constexpr int kOwnLong = 64, kOwnShort = 1024;   // a block's share of the tied words per pass over the list
+constexpr int kNarrowMaxP = 8192;      // 17 partition bitmaps in LDS
+
+__global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *count, const uint32_t *cand,
+                                                 const uint32_t *post_off, const uint32_t *post,
+                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G,
+                                                 int parity)
+{
+    extern __shared__ unsigned char smem[];
+    __shared__ int red[16];
+    __shared__ unsigned wl[16], ws[16];
+    __shared__ uint32_t own_long[kOwnLong], own_short[kOwnShort];
+    __shared__ float acc_s;
+    // stop / need_rebuild are written by block 0 of this very kernel as well: every block reaches the same
+    // verdict from the same inputs, so a block that sees the flag early only skips work it would have skipped
+    if (st->stop || st->need_rebuild) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int words = (P + 31) / 32;
+    unsigned *seen_blk = (unsigned *)smem;
+    unsigned *seen_w = seen_blk + (size_t)words * (1 + wave);
+    const int n_win = st->n_win;
+    if (n_win >= st->max_iter || st->stop_next) {   // main.rs:344-366
+        if (blockIdx.x == 0 && tid == 0) st->stop = 1;
+        return;
+    }
+    const unsigned n_cand = st->n_cand;
+    int m = 0;
+    for (unsigned i = tid; i < n_cand; i += 1024) m = max(m, count[cand[i]]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
 #pragma unroll
-            for (int u = 0; u < kTieUnroll; ++u) {
-                const uint32_t i = base + u * 1024 + threadIdx.x;
-                seg[u] = i < e ? post[i] : 0xffffffffu;
+    for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+    if (m < st->theta) {   // a word outside the list may be ahead now
+        if (blockIdx.x == 0 && tid == 0) st->need_rebuild = 1;
+        return;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long best = 0;
+    for (unsigned pass = 0;; ++pass) {
+        // number the tied words (long and short posting lists apart) in list order; word t of a class
+        // belongs to block t % gridDim.x
+        unsigned tot_l = 0, tot_s = 0;
+        for (unsigned base = 0; base < n_cand; base += 1024) {
+            const unsigned i = base + (unsigned)tid;
+            uint32_t kid = 0;
+            bool hit = false, is_long = false;
+            if (i < n_cand) {
+                kid = cand[i];
+                hit = count[kid] == m;
+                if (hit) is_long = post_off[kid + 1] - post_off[kid] > kLongList;
             }
+            const unsigned long long bl = __ballot(is_long), bs = __ballot(hit && !is_long);
+            if (lane == 0) {
+                wl[wave] = (unsigned)__popcll(bl);
+                ws[wave] = (unsigned)__popcll(bs);
+            }
+            __syncthreads();
+            unsigned pl = tot_l, ps = tot_s;
 #pragma unroll
-            for (int u = 0; u < kTieUnroll; ++u)
-                live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
-#pragma unroll
-            for (int u = 0; u < kTieUnroll; ++u) {
-                const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
-                const int ps = live[u] ? part : 0;   // in-bounds bitmap index for idle lanes
-                bool fresh = live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u);
-                if (__syncthreads_or(fresh)) {
-                    for (int w = 0; w < 16; ++w) {
-                        if (wave == w) {
-                            // partitions taken by the earlier waves of this chunk are visible now
-                            if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
-                            unsigned long long m = __ballot(fresh);
-                            float acc = acc_s;
-                            while (m) {
-                                const int l = __ffsll((long long)m) - 1;
-                                const int pl = __shfl(part, l);
-                                m &= ~__ballot(part == pl);
-                                if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
-                                acc += 1.0f / ((float)coverage[pl] + 1.0f);
-                            }
-                            if (lane == 0) acc_s = acc;
-                        }
-                        __syncthreads();
+            for (int w = 0; w < 16; ++w) {
+                const unsigned a = wl[w], c = ws[w];
+                if (w < wave) {
+                    pl += a;
+                    ps += c;
+                }
+                tot_l += a;
+                tot_s += c;
+            }
+            if (hit) {
+                const unsigned t = is_long ? pl + (unsigned)__popcll(bl & below) : ps + (unsigned)__popcll(bs & below);
+                if (t % gridDim.x == blockIdx.x) {
+                    const unsigned o = t / gridDim.x;
+                    if (is_long) {
+                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = kid;
+                    } else {
+                        if (o / kOwnShort == pass) own_short[o % kOwnShort] = kid;
                     }
                 }
             }
+            __syncthreads();   // wl / ws are rewritten by the next round; the lists are complete after the last
         }
-        if (threadIdx.x == 0) atomicMax(&st->best, winner_key(acc_s, kid));
-        __syncthreads();
+        const unsigned my_l = tot_l > blockIdx.x ? (tot_l - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        const unsigned my_s = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
+            if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
+            break;
+        }
+        const unsigned nl = my_l > pass * kOwnLong ? min(my_l - pass * kOwnLong, (unsigned)kOwnLong) : 0;
+        const unsigned ns = my_s > pass * kOwnShort ? min(my_s - pass * kOwnShort, (unsigned)kOwnShort) : 0;
+        for (unsigned j = 0; j < nl; ++j) {
+            const uint32_t kid = own_long[j];
+            tie_score_block(kid, seen_blk, &acc_s, words, post_off, post, ignored, coverage, P, G);
+            if (tid == 0) {
+                const unsigned long long key = winner_key(acc_s, kid);
+                best = key > best ? key : best;
+            }
+            __syncthreads();
+        }
+        for (unsigned j = wave; j < ns; j += 16) {
+            const uint32_t kid = own_short[j];
+            const float acc = tie_score_wave(kid, seen_w, words, lane, post_off, post, ignored, coverage, P, G);
+            const unsigned long long key = winner_key(acc, kid);
+            best = key > best ? key : best;
+        }
+        if ((pass + 1) * kOwnLong >= my_l && (pass + 1) * kOwnShort >= my_s) break;
+        __syncthreads();   // the lists are rewritten by the next pass
+    }
+    if (lane == 0 && best) atomicMax(&st->best2[parity], best);
+    if (blockIdx.x == 0 && tid == 0) {
+        st->maxf = m;
+        st->it1 = (unsigned)n_win + 1u;
+        st->best2[parity ^ 1] = 0;   // the next iteration's; k_cover of the last one is over
     }
 }
 
@@ -399,19 +583,33 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
 // postings are the same window of near-identical genomes, so equal targets are merged across the
 // wave before the atomic (same-address atomics serialise in L2).  The last block records the
 // winner.
+// kNarrow: the candidate-list loop's variant.  The winner comes from best2[parity], the stamp from it1, and
+// block 0 records the winner on its own (nothing else in this kernel reads the fields it writes; k_select of
+// the next iteration does), so there is no last-block step.
+template <bool kNarrow>
 __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_off,
                                                const uint32_t *post, uint8_t *ignored,
                                                uint32_t *coverage, uint32_t *stamp, int P, int G,
                                                int per, const int32_t *kid_of_inst, int32_t *count,
                                                const uint64_t *ukeys, uint64_t *out_key,
-                                               uint32_t *out_freq)
+                                               uint32_t *out_freq, int parity)
 {
     __shared__ int32_t tile[64 * 33];
     __shared__ uint32_t rows_s[64];   // partition-major row of each posting, ~0u: nothing to do
     __shared__ int any_live;
-    if (st->stop) return;
-    const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
-    const uint32_t kid = 0xffffffffu - (uint32_t)(st->best & 0xffffffffull);
+    if (st->stop || (kNarrow && st->need_rebuild)) return;
+    const uint32_t it1 = kNarrow ? st->it1 : (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
+    const unsigned long long best = kNarrow ? st->best2[parity] : st->best;
+    const uint32_t kid = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
+    if (kNarrow && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int mf = st->maxf, nw = st->n_win;
+        out_key[nw] = ukeys[kid];
+        out_freq[nw] = (uint32_t)mf;
+        st->winner = (int)kid;
+        st->n_win = nw + 1;
+        if (mf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
+        st->maxf = 0;   // k_max_count starts from zero
+    }
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
@@ -475,7 +673,7 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
         __syncthreads();   // rows_s / any_live are rewritten by the next group
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (!kNarrow && threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
             const int mf = st->maxf;
@@ -637,7 +835,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
         (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
         (rc = ensure(12, (size_t)P * 8, err)) ||
-        (rc = ensure(13, 64 + (size_t)opt.max_iterations * 12, err)))
+        (rc = ensure(13, 128 + (size_t)opt.max_iterations * 12, err)))
         return rc;
     uint64_t *key_a = (uint64_t *)buf_[0], *key_b = (uint64_t *)buf_[1];
     uint32_t *val_a = (uint32_t *)buf_[2], *val_b = (uint32_t *)buf_[3];
@@ -650,7 +848,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     uint8_t *ignored = (uint8_t *)buf_[11];
     uint32_t *coverage = (uint32_t *)buf_[12], *stamp = coverage + P;
     Status *st = (Status *)buf_[13];
-    uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 64);
+    uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 128);
     uint32_t *out_freq = (uint32_t *)(out_key + opt.max_iterations);
 
     // 1. extraction
@@ -704,52 +902,82 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     h0.min_freq = opt.max_mismatch_segments;
     KM_TRY(hipMemcpyAsync(st, &h0, sizeof h0, hipMemcpyHostToDevice, stream));
     KM_TRY(hipStreamSynchronize(stream));
-    auto enqueue_iteration = [&](hipStream_t s_) {
-        hipLaunchKernelGGL(k_max_count, dim3(red_grid), dim3(256), 0, s_, count, M, st);
+    auto enqueue_iteration = [&](hipStream_t s_, int /*node*/) {
+        hipLaunchKernelGGL(k_max_count<false>, dim3(red_grid), dim3(256), 0, s_, count, M, st);
         hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
                            post_off, tied);
         hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
                            ignored, coverage, (int)P, n_seq);
         hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
                            post, ignored, coverage, (int)P, n_seq);
-        hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq);
+        hipLaunchKernelGGL(k_cover<false>, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
+                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, 0);
+    };
+    // the candidate-list iteration (two launches); `tied` doubles as the candidate list
+    uint32_t *cand = tied;
+    const size_t sel_lds = 17 * sizeof(unsigned) * (size_t)((P + 31) / 32);
+    auto enqueue_narrow = [&](hipStream_t s_, int node) {
+        hipLaunchKernelGGL(k_select, dim3(kSelectGrid), dim3(1024), sel_lds, s_, st, count, cand, post_off, post,
+                           ignored, coverage, (int)P, n_seq, node & 1);
+        hipLaunchKernelGGL(k_cover<true>, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
+                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, node & 1);
     };
     // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration:
     // 29 -> 27 ms per direction at 10,000 genomes)
     constexpr int kBatch = 32;
-    GraphGuard gg;
-    hipGraph_t &graph = gg.graph;
-    hipGraphExec_t &exec = gg.exec;
+    GraphGuard gg[2];   // 0: five-launch iterations, 1: candidate-list iterations
     bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
-    if (use_graph) {
+    auto capture = [&](int which) -> bool {
         // capture on a private stream so that the caller's stream may be of any kind
         hipStream_t cs = nullptr;
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) use_graph = false;
-        if (use_graph && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int b = 0; b < kBatch; ++b) enqueue_iteration(cs);
-            if (hipStreamEndCapture(cs, &graph) != hipSuccess || !graph ||
-                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
-                use_graph = false;
+        bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+        if (ok && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int b = 0; b < kBatch; ++b) which ? enqueue_narrow(cs, b) : enqueue_iteration(cs, b);
+            ok = hipStreamEndCapture(cs, &gg[which].graph) == hipSuccess && gg[which].graph &&
+                 hipGraphInstantiate(&gg[which].exec, gg[which].graph, nullptr, nullptr, 0) == hipSuccess;
         } else {
-            use_graph = false;
+            ok = false;
         }
         if (cs) (void)hipStreamDestroy(cs);
         (void)hipGetLastError();
-    }
+        return ok;
+    };
+    const bool narrow_ok = narrow_loop_ && P <= kNarrowMaxP;
     Status h = h0;
-    for (int done = 0; done < h0.max_iter + 1 && !h.stop; done += kBatch) {
+    for (int done = 0; done < h0.max_iter + 2 && !h.stop; ++done) {
+        int which = 0;
+        if (narrow_ok) {
+            // head of the batch: the maximum, theta and the candidate list (and the stop decision)
+            hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, stream, count, M, st);
+            hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, stream, count, M, st, cand);
+            KM_TRY(hipGetLastError());
+            KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
+            KM_TRY(hipStreamSynchronize(stream));
+            if (h.stop) break;
+            which = h.n_cand <= kCandCap ? 1 : 0;
+        } else if (done * kBatch >= h0.max_iter + 1) {
+            break;
+        }
+        if (use_graph && !gg[which].exec && !capture(which)) use_graph = false;
         if (use_graph) {
-            KM_TRY(hipGraphLaunch(exec, stream));
+            KM_TRY(hipGraphLaunch(gg[which].exec, stream));
         } else {
-            for (int b = 0; b < kBatch; ++b) enqueue_iteration(stream);
+            for (int b = 0; b < kBatch; ++b) which ? enqueue_narrow(stream, b) : enqueue_iteration(stream, b);
         }
         KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
     }
     const int n_win = h.n_win;
-    if (h.maxf > 1 && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
+    if (narrow_ok && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
+        // the candidate-list loop stops at max_iter without looking at the words: is anything left?
+        KM_TRY(hipMemsetAsync((char *)st + offsetof(Status, stop), 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, stream, count, M, st);
+        KM_TRY(hipGetLastError());
+        KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipStreamSynchronize(stream));
+    }
+    if (h.last_max > 1 && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
         // the caller's buffers ended the loop, not the reference's rules
         err = "stage A: more winners than the caller's capacity";
         return MSSPE_ERR_CAPACITY;

@@ -43,11 +43,14 @@ public:
                  uint8_t *hit_out, hipStream_t stream, std::string &err);
     void release();
     void set_use_graph(bool on) { use_graph_ = on; }
+    // false: every iteration of the greedy loop scans all the words (the five-launch iteration)
+    void set_narrow_loop(bool on) { narrow_loop_ = on; }
 
 private:
     void *buf_[16] = {};
     size_t cap_[16] = {};
     bool use_graph_ = true;
+    bool narrow_loop_ = true;
     int ensure(int slot, size_t bytes, std::string &err);
 };
 

@@ -134,6 +134,29 @@ def test_plain_launches_instead_of_graph_replays(eng, m, oracle, monkeypatch):
         eng.set_option("stage_a_graph", 1)
 
 
+def test_candidate_list_loop_equals_the_all_words_loop(eng, m, oracle):
+    """The two greedy-loop drivers (option stage_a_candidates: the list of words near the maximum, rebuilt
+    whenever the maximum halves, against a scan of every word on every iteration) pick the same winners
+    with the same frequencies, to the last iteration (frequency 2), with graph replays and without."""
+    cases = [(m.synth.aligned_genomes(400, 9000), m.KmerOpt(500, 250, 50, 13, 1000, 1)),
+             (m.synth.aligned_genomes(120, 3000), m.KmerOpt(300, 100, 40, 6, 1000, 1)),
+             (m.synth.aligned_genomes(900, 30000), m.KmerOpt(500, 250, 50, 13, 300, 3))]
+    for arr, opt in cases:
+        for d in (0, 1):
+            res = {}
+            for cand, graph in ((0, 1), (1, 1), (1, 0)):
+                eng.set_option("stage_a_candidates", cand)
+                eng.set_option("stage_a_graph", graph)
+                try:
+                    got = eng.kmer_candidates(arr, opt, d)
+                finally:
+                    eng.set_option("stage_a_candidates", 1)
+                    eng.set_option("stage_a_graph", 1)
+                res[(cand, graph)] = (list(got[0]), got[1].tolist())
+            assert res[(0, 1)] == res[(1, 1)] == res[(1, 0)]
+            assert len(res[(1, 1)][0]) > 20
+
+
 def test_long_posting_lists_and_ties(eng, m, oracle):
     """700 near-identical rows: posting lists of thousands of segments spread over many partitions
     (k = 3) tie at the same frequency, so the block-per-word scoring kernel, its ordered path and
