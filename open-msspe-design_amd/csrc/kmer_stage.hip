@@ -28,6 +28,11 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
 
+// development aid: knock-outs for timing experiments (wrong results), see tools/variant_build_file.sh
+#ifndef MSSPE_SA_KO
+#define MSSPE_SA_KO 0
+#endif
+
 namespace msspe {
 
 namespace {
@@ -52,6 +57,7 @@ struct Status {
     int need_rebuild;  // 1: the candidates' maximum fell below theta; the rest of the batch is a no-op
     unsigned it1;      // stamp of the iteration in flight (n_win + 1)
     int last_max;      // the maximum the last k_max_count saw (the host's capacity check)
+    int too_many;      // 1: the candidate list is longer than k_select reads; the host runs a five-launch batch
     unsigned long long best2[2];   // `best` of the candidate-list loop, alternating with the iteration
 };
 static_assert(sizeof(Status) <= 128, "the winners' arrays start 128 bytes into the status buffer");
@@ -249,6 +255,7 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
                 st->theta = max(2, mf / 2);
                 st->n_cand = 0;
                 st->need_rebuild = 0;
+                st->too_many = 0;
                 st->maxf = 0;
                 st->best2[0] = 0;
                 st->best2[1] = 0;
@@ -286,8 +293,12 @@ __global__ void __launch_bounds__(256) k_collect_tied(const int32_t *count, int 
     }
 }
 
-// Words with a live count of at least theta, in any order (wave-aggregated append).
-__global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int M, Status *st, uint32_t *cand)
+// Words with a live count of at least theta, in any order (wave-aggregated append); bit 31 marks a long
+// posting list (the class k_tie_long / tie_score_block serves).
+constexpr uint32_t kCandLong = 0x80000000u;
+
+__global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int M, Status *st,
+                                                      const uint32_t *post_off, uint32_t *cand)
 {
     if (st->stop) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,7 +310,9 @@ __global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int 
         unsigned base = 0;
         if (lane == first) base = atomicAdd(&st->n_cand, (unsigned)__popcll(mh));
         base = __shfl(base, first);
-        if (hit) cand[base + (unsigned)__popcll(mh & ((1ull << lane) - 1ull))] = (uint32_t)i;
+        if (hit)
+            cand[base + (unsigned)__popcll(mh & ((1ull << lane) - 1ull))] =
+                (uint32_t)i | (post_off[i + 1] - post_off[i] > kLongList ? kCandLong : 0u);
     }
 }
 
@@ -318,26 +331,33 @@ __device__ __forceinline__ float tie_score_wave(uint32_t kid, unsigned *seen, in
                                                 const uint32_t *post_off, const uint32_t *post,
                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G)
 {
+    constexpr int kDeep = 8;   // 64-posting chunks whose (post -> ignored) loads are in flight together
     for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     float acc = 0.0f;
-    for (uint32_t base = b; base < e; base += 64) {
-        const uint32_t i = base + lane;
-        bool fresh = false;
-        int part = -1;
-        if (i < e) {
-            const uint32_t seg = post[i];
-            part = (int)(seg % (uint32_t)P);
-            fresh = !ignored[(uint32_t)part * (uint32_t)G + seg / (uint32_t)P] &&
-                    !((seen[part >> 5] >> (part & 31)) & 1u);
+    for (uint32_t base = b; base < e; base += 64 * kDeep) {
+        uint32_t seg[kDeep];
+        bool live[kDeep];
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            const uint32_t i = base + u * 64 + lane;
+            seg[u] = i < e ? post[i] : 0xffffffffu;
         }
-        unsigned long long m = __ballot(fresh);
-        while (m) {   // wave-uniform: distinct new partitions in ascending posting order
-            const int l = __ffsll((long long)m) - 1;
-            const int pl = __shfl(part, l);
-            m &= ~__ballot(part == pl);
-            if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
-            acc += 1.0f / ((float)coverage[pl] + 1.0f);
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u)
+            live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int ps = live[u] ? part : 0;
+            unsigned long long m = __ballot(live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u));
+            while (m) {   // wave-uniform: distinct new partitions in ascending posting order
+                const int l = __ffsll((long long)m) - 1;
+                const int pl = __shfl(part, l);
+                m &= ~__ballot(part == pl);
+                if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
+                acc += 1.0f / ((float)coverage[pl] + 1.0f);
+            }
         }
     }
     return acc;
@@ -369,18 +389,33 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
 }
 
 // The same walk for a long posting list, by a whole 1024-thread block: the block loads and
-// filters 1024 postings at a time; only chunks that hold a not-yet-seen partition (normally just
-// the first) take the ordered path, where the 16 waves resolve their candidates in turn.
-// Every thread of the block calls it; the score is in *acc_s afterwards.
-__device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, float *acc_s, int words,
+// filters 1024 postings at a time.  A chunk that holds not-yet-seen partitions (normally just the first
+// chunk, and one partition) gives them up one at a time, earliest posting first: the block finds the
+// smallest thread index among the fresh postings and that thread adds its partition's term.  A chunk with
+// many new partitions goes over to the ordered path after kExtract rounds, where the 16 waves resolve
+// their candidates in turn.  Every thread of the block calls it; the score is in sh->acc afterwards.
+struct TieBlockShared {
+    float acc;
+    int first[3];   // smallest fresh thread index; round r uses first[r % 3]
+    int part;       // the partition being taken
+};
+
+__device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, TieBlockShared *sh, int words,
                                                 const uint32_t *post_off, const uint32_t *post,
                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G)
 {
+    constexpr int kExtract = 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int wd = threadIdx.x; wd < words; wd += 1024) seen[wd] = 0u;
-    if (threadIdx.x == 0) *acc_s = 0.0f;
+    if (threadIdx.x == 0) {
+        sh->acc = 0.0f;
+        sh->first[0] = 0x7fffffff;
+        sh->first[1] = 0x7fffffff;
+        sh->first[2] = 0x7fffffff;
+    }
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     __syncthreads();
+    int slot = 0;
     for (uint32_t base = b; base < e; base += 1024 * kTieUnroll) {
         // kTieUnroll chunks of (post -> ignored) dependent loads in flight at once
         uint32_t seg[kTieUnroll];
@@ -398,13 +433,36 @@ __device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, fl
             const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
             const int ps = live[u] ? part : 0;   // in-bounds bitmap index for idle lanes
             bool fresh = live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u);
-            if (__syncthreads_or(fresh)) {
+            bool more = true;
+            for (int round = 0; round < kExtract; ++round) {
+                // first[slot] is 0x7fffffff here and nobody reads it any more: it was reset two rounds ago,
+                // after the barrier that followed its last read
+                const unsigned long long mf = __ballot(fresh);
+                if (mf && lane == __ffsll((long long)mf) - 1) atomicMin(&sh->first[slot], (int)threadIdx.x);
+                __syncthreads();
+                const int f = sh->first[slot];
+                const int prev = slot == 0 ? 2 : slot - 1;
+                if (threadIdx.x == 0) sh->first[prev] = 0x7fffffff;   // its readers are all past the barrier
+                slot = slot == 2 ? 0 : slot + 1;
+                if (f == 0x7fffffff) {   // block-uniform: nothing fresh is left in this chunk
+                    more = false;
+                    break;
+                }
+                if ((int)threadIdx.x == f) {
+                    sh->part = part;
+                    seen[part >> 5] |= 1u << (part & 31);
+                    sh->acc += 1.0f / ((float)coverage[part] + 1.0f);
+                }
+                __syncthreads();
+                if (part == sh->part) fresh = false;
+            }
+            if (more && __syncthreads_or(fresh)) {
                 for (int w = 0; w < 16; ++w) {
                     if (wave == w) {
                         // partitions taken by the earlier waves of this chunk are visible now
                         if (fresh) fresh = !((seen[ps >> 5] >> (ps & 31)) & 1u);
                         unsigned long long m = __ballot(fresh);
-                        float acc = *acc_s;
+                        float acc = sh->acc;
                         while (m) {
                             const int l = __ffsll((long long)m) - 1;
                             const int pl = __shfl(part, l);
@@ -412,7 +470,7 @@ __device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, fl
                             if (lane == 0) seen[pl >> 5] |= 1u << (pl & 31);
                             acc += 1.0f / ((float)coverage[pl] + 1.0f);
                         }
-                        if (lane == 0) *acc_s = acc;
+                        if (lane == 0) sh->acc = acc;
                     }
                     __syncthreads();
                 }
@@ -428,7 +486,7 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
                                                    int P, int G)
 {
     extern __shared__ unsigned char smem[];
-    __shared__ float acc_s;
+    __shared__ TieBlockShared tb;
     if (st->stop) return;
     unsigned *seen = (unsigned *)smem;
     const int words = (P + 31) / 32;
@@ -440,8 +498,8 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
     }
     for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
         const uint32_t kid = tied[(unsigned)M - 1u - j];
-        tie_score_block(kid, seen, &acc_s, words, post_off, post, ignored, coverage, P, G);
-        if (threadIdx.x == 0) atomicMax(&st->best, winner_key(acc_s, kid));
+        tie_score_block(kid, seen, &tb, words, post_off, post, ignored, coverage, P, G);
+        if (threadIdx.x == 0) atomicMax(&st->best, winner_key(tb.acc, kid));
         __syncthreads();
     }
 }
@@ -465,11 +523,13 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
                                                  const uint8_t *ignored, const uint32_t *coverage, int P, int G,
                                                  int parity)
 {
+    constexpr int kKeep = 4;   // rounds of 1024 candidates whose (word, count) stay in registers
     extern __shared__ unsigned char smem[];
     __shared__ int red[16];
-    __shared__ unsigned wl[16], ws[16];
+    __shared__ unsigned wl[kKeep * 16], ws[kKeep * 16];   // tied words per (round, wave), then their prefix sums
+    __shared__ unsigned tot_sh[2];
     __shared__ uint32_t own_long[kOwnLong], own_short[kOwnShort];
-    __shared__ float acc_s;
+    __shared__ TieBlockShared tb;
     // stop / need_rebuild are written by block 0 of this very kernel as well: every block reaches the same
     // verdict from the same inputs, so a block that sees the flag early only skips work it would have skipped
     if (st->stop || st->need_rebuild) return;
@@ -483,8 +543,27 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
         return;
     }
     const unsigned n_cand = st->n_cand;
+    if (n_cand > kCandCap) {   // every block reads the whole list: too long for that, the host goes the other way
+        if (blockIdx.x == 0 && tid == 0) {
+            st->need_rebuild = 1;
+            st->too_many = 1;
+        }
+        return;
+    }
+    // the first kKeep rounds of the list stay in registers for the second look
+    uint32_t ck[kKeep];
+    int cc[kKeep];
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r) {
+        const unsigned i = (unsigned)r * 1024u + (unsigned)tid;
+        ck[r] = i < n_cand ? cand[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r) cc[r] = ck[r] != 0xffffffffu ? count[ck[r] & ~kCandLong] : 0;
     int m = 0;
-    for (unsigned i = tid; i < n_cand; i += 1024) m = max(m, count[cand[i]]);
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r) m = max(m, cc[r]);
+    for (unsigned i = kKeep * 1024u + (unsigned)tid; i < n_cand; i += 1024) m = max(m, count[cand[i] & ~kCandLong]);
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if (lane == 0) red[wave] = m;
     __syncthreads();
@@ -496,63 +575,114 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
         return;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
+    // number the tied words (long and short posting lists apart) in list order; word t of a class belongs
+    // to block t % gridDim.x, which keeps its share in own_long / own_short (kOwn* words per pass)
+    unsigned long long bl[kKeep], bs[kKeep];
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r) {
+        const bool hit = cc[r] == m;   // m >= 2: the padding (count 0) never hits
+        const bool lg = hit && (ck[r] & kCandLong);
+        bl[r] = __ballot(lg);
+        bs[r] = __ballot(hit && !lg);
+        if (lane == 0) {
+            wl[r * 16 + wave] = (unsigned)__popcll(bl[r]);
+            ws[r * 16 + wave] = (unsigned)__popcll(bs[r]);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {   // exclusive prefix sums over the kKeep * 16 (round, wave) cells, in list order
+        unsigned a = wl[lane], c = ws[lane];
+        unsigned ia = a, ic = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned ta = __shfl_up(ia, off), tc = __shfl_up(ic, off);
+            if (lane >= off) {
+                ia += ta;
+                ic += tc;
+            }
+        }
+        wl[lane] = ia - a;
+        ws[lane] = ic - c;
+        if (lane == 63) {
+            tot_sh[0] = ia;
+            tot_sh[1] = ic;
+        }
+    }
+    __syncthreads();
+    const unsigned keep_l = tot_sh[0], keep_s = tot_sh[1];
     unsigned long long best = 0;
     for (unsigned pass = 0;; ++pass) {
-        // number the tied words (long and short posting lists apart) in list order; word t of a class
-        // belongs to block t % gridDim.x
-        unsigned tot_l = 0, tot_s = 0;
-        for (unsigned base = 0; base < n_cand; base += 1024) {
+#pragma unroll
+        for (int r = 0; r < kKeep; ++r) {
+            const bool hit = cc[r] == m;
+            if (hit) {
+                const bool lg = (ck[r] & kCandLong) != 0;
+                const unsigned t = lg ? wl[r * 16 + wave] + (unsigned)__popcll(bl[r] & below)
+                                      : ws[r * 16 + wave] + (unsigned)__popcll(bs[r] & below);
+                if (t % gridDim.x == blockIdx.x) {
+                    const unsigned o = t / gridDim.x;
+                    if (lg) {
+                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = ck[r] & ~kCandLong;
+                    } else {
+                        if (o / kOwnShort == pass) own_short[o % kOwnShort] = ck[r];
+                    }
+                }
+            }
+        }
+        unsigned tot_l = keep_l, tot_s = keep_s;
+        for (unsigned base = kKeep * 1024u; base < n_cand; base += 1024) {   // the rest of a long list
             const unsigned i = base + (unsigned)tid;
             uint32_t kid = 0;
-            bool hit = false, is_long = false;
+            bool hit = false, lg = false;
             if (i < n_cand) {
                 kid = cand[i];
-                hit = count[kid] == m;
-                if (hit) is_long = post_off[kid + 1] - post_off[kid] > kLongList;
+                hit = count[kid & ~kCandLong] == m;
+                lg = hit && (kid & kCandLong);
             }
-            const unsigned long long bl = __ballot(is_long), bs = __ballot(hit && !is_long);
-            if (lane == 0) {
-                wl[wave] = (unsigned)__popcll(bl);
-                ws[wave] = (unsigned)__popcll(bs);
-            }
+            const unsigned long long xl = __ballot(lg), xs = __ballot(hit && !lg);
+            __syncthreads();   // red is read by everybody before it is rewritten
+            if (lane == 0) red[wave] = (int)((unsigned)__popcll(xl) << 16 | (unsigned)__popcll(xs));
             __syncthreads();
             unsigned pl = tot_l, ps = tot_s;
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                const unsigned a = wl[w], c = ws[w];
+                const unsigned v = (unsigned)red[w];
                 if (w < wave) {
-                    pl += a;
-                    ps += c;
+                    pl += v >> 16;
+                    ps += v & 0xffffu;
                 }
-                tot_l += a;
-                tot_s += c;
+                tot_l += v >> 16;
+                tot_s += v & 0xffffu;
             }
             if (hit) {
-                const unsigned t = is_long ? pl + (unsigned)__popcll(bl & below) : ps + (unsigned)__popcll(bs & below);
+                const unsigned t = lg ? pl + (unsigned)__popcll(xl & below) : ps + (unsigned)__popcll(xs & below);
                 if (t % gridDim.x == blockIdx.x) {
                     const unsigned o = t / gridDim.x;
-                    if (is_long) {
-                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = kid;
+                    if (lg) {
+                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = kid & ~kCandLong;
                     } else {
                         if (o / kOwnShort == pass) own_short[o % kOwnShort] = kid;
                     }
                 }
             }
-            __syncthreads();   // wl / ws are rewritten by the next round; the lists are complete after the last
         }
+        __syncthreads();   // the lists are complete
         const unsigned my_l = tot_l > blockIdx.x ? (tot_l - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
         const unsigned my_s = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
         if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
             if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
             break;
         }
-        const unsigned nl = my_l > pass * kOwnLong ? min(my_l - pass * kOwnLong, (unsigned)kOwnLong) : 0;
-        const unsigned ns = my_s > pass * kOwnShort ? min(my_s - pass * kOwnShort, (unsigned)kOwnShort) : 0;
+        unsigned nl = my_l > pass * kOwnLong ? min(my_l - pass * kOwnLong, (unsigned)kOwnLong) : 0;
+        unsigned ns = my_s > pass * kOwnShort ? min(my_s - pass * kOwnShort, (unsigned)kOwnShort) : 0;
+        if (MSSPE_SA_KO & 4) {   // no scoring: the first word of each block's share wins
+            if (tid == 0 && (nl || ns)) best = winner_key(1.0f, nl ? own_long[0] : own_short[0]);
+            nl = ns = 0;
+        }
         for (unsigned j = 0; j < nl; ++j) {
             const uint32_t kid = own_long[j];
-            tie_score_block(kid, seen_blk, &acc_s, words, post_off, post, ignored, coverage, P, G);
+            tie_score_block(kid, seen_blk, &tb, words, post_off, post, ignored, coverage, P, G);
             if (tid == 0) {
-                const unsigned long long key = winner_key(acc_s, kid);
+                const unsigned long long key = winner_key(tb.acc, kid);
                 best = key > best ? key : best;
             }
             __syncthreads();
@@ -578,8 +708,8 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
 // partition (main.rs:371-378, covered segments included) and, for segments covered now, take
 // one off the live count of every word they hold.
 // A block takes 64 postings at a time.  Wave 0 does the per-posting bookkeeping; the four waves
-// then gather the 64 segments' word ids into an LDS tile (32 window positions per pass, 128-byte
-// half-row loads) and split the window positions between them with lane = posting: neighbouring
+// then gather the 64 segments' word ids into an LDS tile (64 window positions per pass, 16 loads per
+// thread in flight) and split the window positions between them with lane = posting: neighbouring
 // postings are the same window of near-identical genomes, so equal targets are merged across the
 // wave before the atomic (same-address atomics serialise in L2).  The last block records the
 // winner.
@@ -594,7 +724,7 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                                                const uint64_t *ukeys, uint64_t *out_key,
                                                uint32_t *out_freq, int parity)
 {
-    __shared__ int32_t tile[64 * 33];
+    __shared__ int32_t tile[64 * 65];
     __shared__ uint32_t rows_s[64];   // partition-major row of each posting, ~0u: nothing to do
     __shared__ int any_live;
     if (st->stop || (kNarrow && st->need_rebuild)) return;
@@ -613,10 +743,12 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
+        bool rep = false;          // wave 0: this lane speaks for its partition
+        uint32_t old_stamp = it1;
+        int part = -1;
         if (wave == 0) {
             const uint32_t i = base + lane;
             uint32_t row = 0;
-            int part = -1;
             bool live = false;
             if (i < e) {
                 const uint32_t seg = post[i];
@@ -633,28 +765,29 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                 const int l = __ffsll((long long)m) - 1;
                 const int pl = __builtin_amdgcn_readlane(part, l);
                 m &= ~__ballot(part == pl);
-                if (lane == l && atomicExch(&stamp[pl], it1) != it1) atomicAdd(&coverage[pl], 1u);
+                rep = rep || lane == l;
             }
+            // all the partitions at once; the answer is looked at after the count updates are on their way
+            if (rep) old_stamp = atomicExch(&stamp[part], it1);
         }
         __syncthreads();
-        if (any_live) {
-            for (int q0 = 0; q0 < per; q0 += 32) {
-                int32_t v[8];
+        if (any_live && !(MSSPE_SA_KO & 2)) {
+            for (int q0 = 0; q0 < per; q0 += 64) {
+                int32_t v[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {   // 8 loads per thread in flight before the LDS stores
-                    const int r = 8 * j + (threadIdx.x >> 5), q = q0 + (threadIdx.x & 31);
+                for (int j = 0; j < 16; ++j) {   // 16 loads per thread in flight before the LDS stores
+                    const int r = 4 * j + wave, q = q0 + lane;
                     const uint32_t row_r = rows_s[r];
                     const bool ok = row_r != 0xffffffffu && q < per;
                     const int32_t x = kid_of_inst[ok ? (size_t)row_r * per + q : 0];
                     v[j] = ok ? x : -1;
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    tile[(8 * j + (threadIdx.x >> 5)) * 33 + (threadIdx.x & 31)] = v[j];
+                for (int j = 0; j < 16; ++j) tile[(4 * j + wave) * 65 + lane] = v[j];
                 __syncthreads();
-                const int nq = min(32, per - q0);
+                const int nq = min(64, per - q0);
                 for (int qq = wave; qq < nq; qq += 4) {
-                    const int32_t k2 = tile[lane * 33 + qq];
+                    const int32_t k2 = tile[lane * 65 + qq];
                     // merge the common words of this window position (up to three rounds: the
                     // consensus word and its most frequent variants), the rest go one by one
                     unsigned long long mk = __ballot(k2 >= 0);
@@ -662,14 +795,15 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                         const int l = __ffsll((long long)mk) - 1;
                         const int32_t kl = __builtin_amdgcn_readlane(k2, l);
                         const unsigned long long same = __ballot(k2 == kl);
-                        if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
+                        if (!(MSSPE_SA_KO & 1) && lane == l) atomicSub(&count[kl], (int)__popcll(same));
                         mk &= ~same;
                     }
-                    if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
+                    if (!(MSSPE_SA_KO & 1) && ((mk >> lane) & 1ull)) atomicSub(&count[k2], 1);
                 }
                 __syncthreads();
             }
         }
+        if (rep && old_stamp != it1) atomicAdd(&coverage[part], 1u);   // first posting of the partition this iteration
         __syncthreads();   // rows_s / any_live are rewritten by the next group
     }
     __syncthreads();
@@ -917,6 +1051,12 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     uint32_t *cand = tied;
     const size_t sel_lds = 17 * sizeof(unsigned) * (size_t)((P + 31) / 32);
     auto enqueue_narrow = [&](hipStream_t s_, int node) {
+        if (node == 0) {
+            // head of the batch: the maximum, theta and the candidate list (and the stop decision)
+            hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, s_, count, M, st);
+            hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, post_off,
+                               cand);
+        }
         hipLaunchKernelGGL(k_select, dim3(kSelectGrid), dim3(1024), sel_lds, s_, st, count, cand, post_off, post,
                            ignored, coverage, (int)P, n_seq, node & 1);
         hipLaunchKernelGGL(k_cover<true>, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
@@ -944,20 +1084,11 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     };
     const bool narrow_ok = narrow_loop_ && P <= kNarrowMaxP;
     Status h = h0;
-    for (int done = 0; done < h0.max_iter + 2 && !h.stop; ++done) {
-        int which = 0;
-        if (narrow_ok) {
-            // head of the batch: the maximum, theta and the candidate list (and the stop decision)
-            hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, stream, count, M, st);
-            hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, stream, count, M, st, cand);
-            KM_TRY(hipGetLastError());
-            KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
-            KM_TRY(hipStreamSynchronize(stream));
-            if (h.stop) break;
-            which = h.n_cand <= kCandCap ? 1 : 0;
-        } else if (done * kBatch >= h0.max_iter + 1) {
-            break;
-        }
+    int wide_left = 0;   // five-launch batches still to run after a candidate list came out too long
+    for (int batch = 0; !h.stop; ++batch) {
+        if (narrow_ok ? batch >= h0.max_iter + 2 : batch * kBatch >= h0.max_iter + 1) break;
+        const int which = narrow_ok && wide_left == 0 ? 1 : 0;
+        if (wide_left) --wide_left;
         if (use_graph && !gg[which].exec && !capture(which)) use_graph = false;
         if (use_graph) {
             KM_TRY(hipGraphLaunch(gg[which].exec, stream));
@@ -967,6 +1098,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
+        if (which && h.too_many) wide_left = 4;
     }
     const int n_win = h.n_win;
     if (narrow_ok && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """GPU timing of stage A (k-mer candidates) on synthetic alignments (development aid)."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -15,7 +16,13 @@ length = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
 t0 = time.time()
 g = m.synth.aligned_genomes(rows, length)
 print(f"generated {rows} x {length} in {time.time()-t0:.1f} s", flush=True)
+if os.environ.get("MSSPE_PROBE_LIB"):
+    from msspe_amd import capi
+    capi.use_library(os.environ["MSSPE_PROBE_LIB"])
 eng = m.Engine(0)
+for kv in os.environ.get("MSSPE_PROBE_OPTIONS", "").split(","):
+    if kv:
+        eng.set_option(*kv.split("="))
 d = torch.from_numpy(g).cuda()
 opt = m.KmerOpt(500, 250, 50, 13, 1000, max(1, min(10, -(-rows // 50))))
 for direction in (0, 1):
