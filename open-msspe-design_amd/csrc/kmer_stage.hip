@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
 // scores, same winner.
 constexpr unsigned kCandCap = 32768;   // longer lists go the five-launch way: every block reads all of it
 constexpr int kSelectGrid = 128;
-constexpr int kOwnLong = 64, kOwnShort = 1024;   // a block's share of the tied words per pass over the list
+constexpr int kOwn = (int)(kCandCap / kSelectGrid);   // a block's share of the tied words fits: no second pass
 constexpr int kNarrowMaxP = 8192;      // 17 partition bitmaps in LDS
 
 __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *count, const uint32_t *cand,
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
     __shared__ int red[16];
     __shared__ unsigned wl[kKeep * 16], ws[kKeep * 16];   // tied words per (round, wave), then their prefix sums
     __shared__ unsigned tot_sh[2];
-    __shared__ uint32_t own_long[kOwnLong], own_short[kOwnShort];
+    __shared__ uint32_t own_long[kOwn], own_short[kOwn];
     __shared__ TieBlockShared tb;
     // stop / need_rebuild are written by block 0 of this very kernel as well: every block reaches the same
     // verdict from the same inputs, so a block that sees the flag early only skips work it would have skipped
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
     }
     const unsigned long long below = (1ull << lane) - 1ull;
     // number the tied words (long and short posting lists apart) in list order; word t of a class belongs
-    // to block t % gridDim.x, which keeps its share in own_long / own_short (kOwn* words per pass)
+    // to block t % gridDim.x, which keeps its share in own_long / own_short
     unsigned long long bl[kKeep], bs[kKeep];
 #pragma unroll
     for (int r = 0; r < kKeep; ++r) {
@@ -610,74 +610,55 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
     __syncthreads();
     const unsigned keep_l = tot_sh[0], keep_s = tot_sh[1];
     unsigned long long best = 0;
-    for (unsigned pass = 0;; ++pass) {
 #pragma unroll
-        for (int r = 0; r < kKeep; ++r) {
-            const bool hit = cc[r] == m;
-            if (hit) {
-                const bool lg = (ck[r] & kCandLong) != 0;
-                const unsigned t = lg ? wl[r * 16 + wave] + (unsigned)__popcll(bl[r] & below)
-                                      : ws[r * 16 + wave] + (unsigned)__popcll(bs[r] & below);
-                if (t % gridDim.x == blockIdx.x) {
-                    const unsigned o = t / gridDim.x;
-                    if (lg) {
-                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = ck[r] & ~kCandLong;
-                    } else {
-                        if (o / kOwnShort == pass) own_short[o % kOwnShort] = ck[r];
-                    }
-                }
-            }
+    for (int r = 0; r < kKeep; ++r) {
+        const bool hit = cc[r] == m;
+        if (hit) {
+            const bool lg = (ck[r] & kCandLong) != 0;
+            const unsigned t = lg ? wl[r * 16 + wave] + (unsigned)__popcll(bl[r] & below)
+                                  : ws[r * 16 + wave] + (unsigned)__popcll(bs[r] & below);
+            if (t % gridDim.x == blockIdx.x) (lg ? own_long : own_short)[t / gridDim.x] = ck[r] & ~kCandLong;
         }
-        unsigned tot_l = keep_l, tot_s = keep_s;
-        for (unsigned base = kKeep * 1024u; base < n_cand; base += 1024) {   // the rest of a long list
-            const unsigned i = base + (unsigned)tid;
-            uint32_t kid = 0;
-            bool hit = false, lg = false;
-            if (i < n_cand) {
-                kid = cand[i];
-                hit = count[kid & ~kCandLong] == m;
-                lg = hit && (kid & kCandLong);
-            }
-            const unsigned long long xl = __ballot(lg), xs = __ballot(hit && !lg);
-            __syncthreads();   // red is read by everybody before it is rewritten
-            if (lane == 0) red[wave] = (int)((unsigned)__popcll(xl) << 16 | (unsigned)__popcll(xs));
-            __syncthreads();
-            unsigned pl = tot_l, ps = tot_s;
+    }
+    unsigned tot_l = keep_l, tot_s = keep_s;
+    for (unsigned base = kKeep * 1024u; base < n_cand; base += 1024) {   // the rest of a long list
+        const unsigned i = base + (unsigned)tid;
+        uint32_t kid = 0;
+        bool hit = false, lg = false;
+        if (i < n_cand) {
+            kid = cand[i];
+            hit = count[kid & ~kCandLong] == m;
+            lg = hit && (kid & kCandLong);
+        }
+        const unsigned long long xl = __ballot(lg), xs = __ballot(hit && !lg);
+        __syncthreads();   // red is read by everybody before it is rewritten
+        if (lane == 0) red[wave] = (int)((unsigned)__popcll(xl) << 16 | (unsigned)__popcll(xs));
+        __syncthreads();
+        unsigned pl = tot_l, ps = tot_s;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                const unsigned v = (unsigned)red[w];
-                if (w < wave) {
-                    pl += v >> 16;
-                    ps += v & 0xffffu;
-                }
-                tot_l += v >> 16;
-                tot_s += v & 0xffffu;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned v = (unsigned)red[w];
+            if (w < wave) {
+                pl += v >> 16;
+                ps += v & 0xffffu;
             }
-            if (hit) {
-                const unsigned t = lg ? pl + (unsigned)__popcll(xl & below) : ps + (unsigned)__popcll(xs & below);
-                if (t % gridDim.x == blockIdx.x) {
-                    const unsigned o = t / gridDim.x;
-                    if (lg) {
-                        if (o / kOwnLong == pass) own_long[o % kOwnLong] = kid & ~kCandLong;
-                    } else {
-                        if (o / kOwnShort == pass) own_short[o % kOwnShort] = kid;
-                    }
-                }
-            }
+            tot_l += v >> 16;
+            tot_s += v & 0xffffu;
         }
-        __syncthreads();   // the lists are complete
-        const unsigned my_l = tot_l > blockIdx.x ? (tot_l - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-        const unsigned my_s = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-        if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
-            if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
-            break;
+        if (hit) {
+            const unsigned t = lg ? pl + (unsigned)__popcll(xl & below) : ps + (unsigned)__popcll(xs & below);
+            if (t % gridDim.x == blockIdx.x) (lg ? own_long : own_short)[t / gridDim.x] = kid & ~kCandLong;
         }
-        unsigned nl = my_l > pass * kOwnLong ? min(my_l - pass * kOwnLong, (unsigned)kOwnLong) : 0;
-        unsigned ns = my_s > pass * kOwnShort ? min(my_s - pass * kOwnShort, (unsigned)kOwnShort) : 0;
-        if (MSSPE_SA_KO & 4) {   // no scoring: the first word of each block's share wins
-            if (tid == 0 && (nl || ns)) best = winner_key(1.0f, nl ? own_long[0] : own_short[0]);
-            nl = ns = 0;
-        }
+    }
+    __syncthreads();   // the lists are complete
+    // t / gridDim.x < n_cand / gridDim.x <= kOwn: the share always fits
+    const unsigned nl = tot_l > blockIdx.x ? (tot_l - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const unsigned ns = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
+        if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
+    } else if (MSSPE_SA_KO & 4) {   // no scoring: the first word of each block's share wins
+        if (tid == 0 && (nl || ns)) best = winner_key(1.0f, nl ? own_long[0] : own_short[0]);
+    } else {
         for (unsigned j = 0; j < nl; ++j) {
             const uint32_t kid = own_long[j];
             tie_score_block(kid, seen_blk, &tb, words, post_off, post, ignored, coverage, P, G);
@@ -693,8 +674,6 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
             const unsigned long long key = winner_key(acc, kid);
             best = key > best ? key : best;
         }
-        if ((pass + 1) * kOwnLong >= my_l && (pass + 1) * kOwnShort >= my_s) break;
-        __syncthreads();   // the lists are rewritten by the next pass
     }
     if (lane == 0 && best) atomicMax(&st->best2[parity], best);
     if (blockIdx.x == 0 && tid == 0) {

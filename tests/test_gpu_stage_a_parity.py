@@ -157,6 +157,27 @@ def test_candidate_list_loop_equals_the_all_words_loop(eng, m, oracle):
             assert len(res[(1, 1)][0]) > 20
 
 
+def test_candidate_list_too_long_falls_back(eng, m, oracle):
+    """Unrelated genomes, each present twice: a quarter of a million words tie at frequency 2, far more than
+    the candidate-list kernel reads per block, so the loop runs the all-words batches (and retries the list
+    every few batches).  Same winners as the all-words loop alone, and as the oracle on a small case."""
+    rng = np.random.default_rng(23)
+    half = rng.integers(0, 4, (300, 6000))
+    arr = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate([half, half])]
+    opt = m.KmerOpt(500, 250, 50, 13, 900, 1)   # a few hundred chance repeats (frequency 4, 6) come first
+    res = []
+    for cand in (0, 1):
+        eng.set_option("stage_a_candidates", cand)
+        try:
+            got = eng.kmer_candidates(arr, opt, 0)
+        finally:
+            eng.set_option("stage_a_candidates", 1)
+        res.append((list(got[0]), got[1].tolist()))
+    assert res[0] == res[1] and len(res[0][0]) == 900 and res[0][1][-200:] == [2] * 200
+    small = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate([half[:6, :2000], half[:6, :2000]])]
+    run_both(eng, m, oracle, [bytes(r).decode() for r in small], iters=60, mm=1)
+
+
 def test_long_posting_lists_and_ties(eng, m, oracle):
     """700 near-identical rows: posting lists of thousands of segments spread over many partitions
     (k = 3) tie at the same frequency, so the block-per-word scoring kernel, its ordered path and
