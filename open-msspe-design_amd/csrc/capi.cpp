@@ -38,6 +38,7 @@ struct ChemEntry {
     bool fast_ok = false;
     IntTables *d_it = nullptr;    // integer image for the exact-integer kernel
     bool int_ok = false;
+    bool row_ok = false;          // ... and the row-specialised kernel (thal_pairs_row.hip)
     SplitTables *d_st = nullptr;  // long oligos (thal_pairs_split.hip)
     int split_max_k = 0;          // 0: not usable
     int wave_max_k = 0;           // f64 one-wave-per-pair kernel (thal_pairs_wave.hip)
@@ -158,6 +159,7 @@ int chem_entry(msspe_ctx *ctx, const msspe_chem &chem, float threshold, ChemEntr
         HIP_TRY(ctx, hipMemcpy(e.d_ft, ft.get(), sizeof(FastTables), hipMemcpyHostToDevice));
         auto it = std::make_unique<IntTables>();
         e.int_ok = e.fast_ok && build_int_tables(*ft, pairs_fast_max_k(), *it);
+        e.row_ok = e.int_ok && pairs_row_tables_ok(*it);
         HIP_TRY(ctx, hipMalloc((void **)&e.d_it, sizeof(IntTables)));
         HIP_TRY(ctx, hipMemcpy(e.d_it, it.get(), sizeof(IntTables), hipMemcpyHostToDevice));
         auto st = std::make_unique<SplitTables>();
@@ -697,7 +699,7 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
                 a.col1 = col0 + (int)q_end;
                 HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
             } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->opt.split_lanes, ctx->stream));
-            else if (int_stage && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
+            else if (int_stage && ce->row_ok && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
                 HIP_TRY(ctx, launch_pairs_row(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));

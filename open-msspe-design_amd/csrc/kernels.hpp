@@ -124,6 +124,7 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
 hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
                             hipStream_t stream);
 int pairs_row_max_k();
+bool pairs_row_tables_ok(const IntTables &it);   // host: may this chemistry run the row kernel?
 // List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit
 // 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,

@@ -70,6 +70,24 @@ constexpr int kRowTEntries = kRowL2 * kRowA;
 constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
 constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
 constexpr int kNoY = 1 << 28;                    // table entries at or above kNoY / 2 carry this offset: no cell-side term
+// The running minimum of a scan is ONE v_min_f64 on the pair (candidate value : slot word): every vector
+// instruction of this loop issues at the same rate, f64 or not, and a minimum of two 64-bit
+// patterns with the value on top is compare + two selects in one.  For that the patterns must be positive
+// normal doubles ordered like the values: every table entry carries + kRowD, which puts the reachable
+// candidates (|value| < kReach) and the void ones (kRowU instead of kBig in this table and in the cell-side
+// terms) into [2^20, 0x7fefffff] as high words.
+constexpr int kRowD = 350000000;
+constexpr int kRowU = 850000000;                 // "not available" in T: still void (>= kValid) after any reachable predecessor
+static_assert(kRowD - IntTables::kReach >= (1 << 20), "smallest candidate must be a normal double's high word");
+// (a predecessor's value is always a reachable one: pairs_row_tables_ok() admits only chemistries whose end and
+//  stacked-pair terms are all finite, and a cell takes its value from those or from a non-void candidate)
+static_assert((long long)IntTables::kReach + kRowU + IntTables::kReach + kRowD <= 0x7fefffffLL,
+              "largest candidate (valid loop + void cell side + reachable predecessor) must stay a finite double");
+static_assert(kRowU - IntTables::kReach >= IntTables::kValid, "a void entry stays void");
+static_assert((long long)kRowU + kNoY + kRowD < 0x7fffffffLL, "table entries are int32");
+#ifndef MSSPE_ROW_F64MIN
+#define MSSPE_ROW_F64MIN 1
+#endif
 #ifndef MSSPE_ROW_SEG
 #define MSSPE_ROW_SEG 256
 #endif
@@ -152,6 +170,47 @@ __device__ __forceinline__ unsigned row_index(unsigned C, unsigned W)
 #endif
 }
 
+// Running minimum of a scan (all values carry + kRowD): GW = (value : slot word) as one double, G2 = second
+// smallest value so far (two candidates tie for the minimum iff G2 == the minimum at the end).
+struct RowBest {
+#if MSSPE_ROW_F64MIN
+    double GW;
+#else
+    int G, W;
+#endif
+    int G2;
+};
+__device__ __forceinline__ int best_g(const RowBest &b)
+{
+#if MSSPE_ROW_F64MIN
+    return __double2hiint(b.GW);
+#else
+    return b.G;
+#endif
+}
+__device__ __forceinline__ int best_w(const RowBest &b)
+{
+#if MSSPE_ROW_F64MIN
+    return __double2loint(b.GW);
+#else
+    return b.W;
+#endif
+}
+__device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
+{
+    if (!(MSSPE_KO & 1)) b.G2 = med3_i32(best_g(b), b.G2, cand);   // second smallest so far
+#if MSSPE_ROW_F64MIN
+    const double cd = __hiloint2double(cand, Wp);
+    // (asm: fmin() would canonicalise its operands first; both are normal numbers here by construction, and
+    //  idle lanes, whose patterns may be anything, publish nothing)
+    asm("v_min_f64 %0, %1, %2" : "=v"(b.GW) : "v"(b.GW), "v"(cd));
+#else
+    const bool better = cand < b.G;
+    b.G = min(cand, b.G);
+    b.W = better ? Wp : b.W;
+#endif
+}
+
 // The table addresses and the (still outstanding) table values of one chunk of slots.
 struct ChunkLoad {
     unsigned idx[kC];
@@ -175,7 +234,7 @@ __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, con
 // three waves per SIMD and a third of all instructions scalar, waiting, not issue, was the limit).
 template <int NS, int PC = 0>
 __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int near_from, const char *T,
-                                              const RCell &c, RBest &best, IBest &stk, ScanMasks &m,
+                                              const RCell &c, RowBest &best, IBest &stk, ScanMasks &m,
                                               const ChunkLoad &cur)
 {
     if constexpr (PC * kC < NS) {
@@ -193,24 +252,18 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 ? -kNoY : c.yTS);
-                    const int cand = cur.t[e] + y + Gp;   // unavailable: kBig + ..., never below best.G <= kValid
-                    const bool better = cand < best.G;
-                    if (!(MSSPE_KO & 1)) best.G2 = med3_i32(best.G, best.G2, cand);   // second smallest so far
-                    best.G = min(cand, best.G);
-                    best.W = better ? Wp : best.W;
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD ? -kNoY : c.yTS);
+                    const int cand = cur.t[e] + y + Gp;   // unavailable: kRowU + ..., never below the minimum <= kValid (all + kRowD)
+                    take_min(best, cand, Wp);
                 }
             } else {
                 asm volatile("" ::"n"(PC + 64));
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 ? -kNoY : c.yTS);
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD ? -kNoY : c.yTS);
                     const int cand = cur.t[e] + y + Gp;
-                    const bool better = cand < best.G;
-                    if (!(MSSPE_KO & 1)) best.G2 = med3_i32(best.G, best.G2, cand);
-                    best.G = min(cand, best.G);
-                    best.W = better ? Wp : best.W;
+                    take_min(best, cand, Wp);
                     const bool isstk = cur.idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
                     stk.G = isstk ? Gp : stk.G;
                     stk.W = isstk ? Wp : stk.W;
@@ -265,11 +318,15 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         rc.yTS = sh.yts[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)];
         rc.idxStk = ((im1 * 14 + 1) * 4 + (int)((q.s1 >> (2 * im1)) & 3u)) * 4;   // l2 = 0, i - ii = 1, 3 - n2 = base of the cell
         // ---- all earlier slots as predecessors
-        RBest best;
+        RowBest rb;
         IBest stk;
-        best.G = IntTables::kValid;
-        best.G2 = 0x7fffffff;
-        best.W = 0;
+#if MSSPE_ROW_F64MIN
+        rb.GW = __hiloint2double(IntTables::kValid + kRowD, 0);
+#else
+        rb.G = IntTables::kValid + kRowD;
+        rb.W = 0;
+#endif
+        rb.G2 = 0x7fffffff;
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
@@ -279,8 +336,11 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
 #if MSSPE_ROW_PIPELINE
         if (row_start > 0) chunk_issue<NS, 0>(MSSPE_TAB_ARGS, (const char *)sh.T, rc, first);   // wave-uniform
 #endif
-        if (!(MSSPE_KO & 8)) scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, best, stk, sm, first);
-        const bool tie = best.G2 == best.G;   // two loop candidates share the minimum
+        if (!(MSSPE_KO & 8)) scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, rb, stk, sm, first);
+        const bool tie = rb.G2 == best_g(rb);   // two loop candidates share the minimum
+        RBest best;
+        best.G = best_g(rb) - kRowD;
+        best.W = best_w(rb);
         const bool stHave = lane_bit(sm.stHave);
         const CellBases b = cell_bases(q, im1, jm1, c);   // after the scan: nothing of it is live across it
         // ---- thal.c maxTM(): helix extension if it raises Tm (see thal_pairs_int.hip).  Enthalpies in units
@@ -614,17 +674,21 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
             }
             if (v >= IntTables::kValid) hv = 0;
         }
-        sh.T[e] = needs_y ? v : v + kNoY;
+        if (v >= IntTables::kValid) v = kRowU;
+        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD;
         sh.TH[e] = (short)(((hv / 10) << 1) | (needs_y ? 1 : 0));
     }
     if (threadIdx.x < 4) {
-        sh.T[kRowTEntries + threadIdx.x] = IntTables::kBig + kNoY;
+        sh.T[kRowTEntries + threadIdx.x] = kRowU + kNoY + kRowD;
         sh.TH[kRowTEntries + threadIdx.x] = 0;
     }
     if (threadIdx.x < 64) {
         const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
         const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
-        sh.yts[threadIdx.x] = sh.g[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+        {
+            const int y = sh.g[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+            sh.yts[threadIdx.x] = y >= IntTables::kValid ? kRowU : y;   // void stays void, and in range (kRowD)
+        }
         sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
     }
 }
@@ -690,6 +754,17 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
 }  // namespace
 
 int pairs_row_max_k() { return kRowK; }
+
+// The row kernel's running minimum needs every value a cell can publish to be a reachable one (kRowD above):
+// the end terms and the stacked-pair terms must all exist.  Primer3's parameter set has them all; a
+// chemistry that does not goes to the general integer kernel.
+bool pairs_row_tables_ok(const IntTables &it)
+{
+    if (!it.usable) return false;
+    for (int e = FastTables::kEndL; e < FastTables::kWC + 16; ++e)
+        if (it.g[e] >= IntTables::kValid) return false;
+    return true;
+}
 
 hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
                             hipStream_t stream)
