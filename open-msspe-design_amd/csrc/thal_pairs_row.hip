@@ -390,6 +390,9 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         const int Wcell = in ? ((int)((unsigned)(jm1 * kRowA + (im1 << 2) + ((b.po_c >> 4) & 3)) << 17) | (hb & 0x7fff))
                              : kEmptyRowW;   // lanes without a cell here compute garbage and publish an empty slot
         defer |= in ? flags : 0;
+        // an empty slot's value is never a candidate's winner (its word fails every geometry test), but it is
+        // an operand of the sum that v_min_f64 orders: keep it a number the bounds above cover
+        G0 = in ? G0 : 0;
         // ---- terminal pick (strict minimum of dG incl. the right end term, first in slot order)
         {
             const int Gt = G0 + gR;
