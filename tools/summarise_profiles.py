@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import shutil
+import subprocess
 import sys
 from pathlib import Path
 
@@ -16,6 +17,11 @@ kLaunchChecks = 134217728.0            # 2^27 pairs: one full launch
 kProbeChecks = 3.0 * 16384.0 * 16384.0   # tools/perf_probe.py 16384 = three passes over the pool
 KERNEL = "k_pairs_row"
 KERNEL_MATCH = "k_pairs_row<"   # the row-specialised first stage (thal_pairs_row.hip)
+# the commit whose kernels were measured: the last one that touched the kernel sources (pass it as argv[2] when
+# the working tree had uncommitted kernel changes at collection time)
+COMMIT = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
+    ["git", "log", "-1", "--format=%h", "--", "open-msspe-design_amd/csrc"], cwd=ROOT, capture_output=True,
+    text=True).stdout.strip()
 
 
 def pmc(sub):
@@ -70,7 +76,7 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
-    "kernel": KERNEL, "round": int(ROUND[1:]),
+    "kernel": KERNEL, "round": int(ROUND[1:]), "commit": COMMIT,
     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/perf_probe.py 16384",
     "launches_sampled": nf,
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
@@ -93,7 +99,7 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
                           "waiting": c1["SQ_WAIT_ANY"] / c1["SQ_WAVE_CYCLES"]},
     "lds_bank_conflict_share": c2["SQ_LDS_BANK_CONFLICT"] / c2["SQ_LDS_IDX_ACTIVE"],
     "achieved_int32_tops": c1["SQ_INSTS_VALU"] * 64 / (ms1 * 1e-3) / 1e12,
-    "clock_ghz": clock_ghz}, indent=1))
+    "clock_ghz": clock_ghz, "commit": COMMIT, "round": int(ROUND[1:])}, indent=1))
 # VALU issue-rate microbenchmark -> readable table
 vp = RAW / "valu_peak.jsonl"
 if vp.exists():
