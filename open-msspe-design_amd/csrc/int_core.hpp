@@ -20,6 +20,29 @@ constexpr int kSlotsMatrix = 56;   // k <= 16 (the largest tables drag their wav
 constexpr int kSlotsList = 64;     // table of the list-mode kernel (lanes arrive sorted by table size)
 constexpr int kThreadsI = 512;
 constexpr int kPathMax = 16;       // a path has at most k <= 16 cells
+// A tie in the terminal pick: thal() walks from one of the cells that share the minimal DP value g =
+// dH - 310.15 dS.  What it reports for the walked structure is dH - T (dS + salt N) (drawDimer; T = the
+// chemistry's temperature, N = base pairs - 1), i.e. relative to the structure this kernel walked
+//      dG' - dG = (dH' - dH) (1 - T / 310.15) - T salt (N' - N).
+// The enthalpies of all tied cells are known without a walk (the slot words carry them): the pick keeps their
+// range.  When a call asks for decisions only (no dG / Tm planes; the edge list takes conflicts, whose ties are
+// still handed on) and even the lowest value a tied structure could report (the enthalpy at the end of the
+// range that lowers it, N' = 0 for the usual negative salt term, kPathMax - 1 otherwise) stays above the cut
+// by a margin, the pair is final as "no conflict" whichever cell the reference walks from.
+constexpr double kPickMargin = 0.5;   // cal/mol; exact values are multiples of 0.0005
+// dh_min / dh_max: range over the tied cells of (their enthalpy - the walked cell's), in units of 10 cal/mol
+__device__ __forceinline__ bool tied_pick_cannot_conflict(const ThalConsts &K, double G, int N, int dh_min, int dh_max)
+{
+    const double psi = 1.0 - K.temp_k / 310.15;
+    const double dH = psi * 10.0 * (psi >= 0.0 ? (double)min(dh_min, 0) : (double)max(dh_max, 0));   // <= 0
+    const double per = K.temp_k * K.salt;
+    const double dN = per < 0.0 ? per * (double)N : -per * (double)(kPathMax - 1 - N);              // <= 0
+#ifdef MSSPE_PICK_NAIVE   // development aid: the bound without its two terms (wrong; shows what the tests catch)
+    return G > K.g_cut + kPickMargin;
+#else
+    return (G + dH) + dN > K.g_cut + kPickMargin;
+#endif
+}
 constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
 constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test
 

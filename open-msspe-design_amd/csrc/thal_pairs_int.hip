@@ -174,7 +174,7 @@ __device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, int fa
 // handed on, because a second walk would be paid by the whole wave).
 template <int NS, bool RESOLVE, class SH>
 __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, const SeqPair &q,
-                                                  unsigned rowmask, int n_cells, int nmax)
+                                                  unsigned rowmask, int n_cells, int nmax, bool decisions_only)
 {
     const Lds &F = sh.F;
     v32i Ga = 0, Wa = kEmptyW;
@@ -191,7 +191,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
     // first slot of the lane's current row and of its two previous non-empty rows: every slot
     // below row_lo2 lies at least three rows above the current cell
     int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
-    int pickG = 0x7fffffff, pickW = 0, pickW2 = 0, nTie = 0;
+    int pickG = 0x7fffffff, pickW = 0, pickW2 = 0, nTie = 0, tieLo = 0, tieHi = 0;
     unsigned long long softTie = 0ull;   // per lane: slots whose value has an equal-valued alternative
 
     for (int slot_ = 0; slot_ < nmax; ++slot_) {
@@ -284,6 +284,11 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
             const bool pick = in & (Gt < pickG);
             const bool same = in & (Gt == pickG);
             pickW2 = (same & (nTie == 0)) ? Wcell : pickW2;   // the first later cell with the same value
+            {   // range of the tied later cells' enthalpies (right end included, units of 10 cal/mol)
+                const int ht = (H0 + F.H[b.idxR]) / 10;   // both multiples of 10 (build_int_tables)
+                tieLo = same ? ((nTie == 0) ? ht : min(tieLo, ht)) : tieLo;
+                tieHi = same ? ((nTie == 0) ? ht : max(tieHi, ht)) : tieHi;
+            }
             nTie = pick ? 0 : (nTie + (same ? 1 : 0));
             pickG = pick ? Gt : pickG;
             pickW = pick ? Wcell : pickW;
@@ -325,9 +330,9 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
     out.r.conflict = false;
 
     const int nch = (nmax + kC - 1) / kC;
-    defer |= (RESOLVE ? nTie > 1 : nTie > 0) ? kDeferPick : 0;
-    const bool second = RESOLVE && !out.r.none && nTie == 1;
-    const bool any_second = RESOLVE && __builtin_amdgcn_ballot_w64(second) != 0ull;   // wave-uniform
+    // (kDeferPick is decided at the end: int_core.hpp kPickMargin)
+    bool second = RESOLVE && !out.r.none && nTie == 1;
+    bool any_second = RESOLVE && __builtin_amdgcn_ballot_w64(second) != 0ull;   // wave-uniform
 
     // ---- walk from the picked cell (and, RESOLVE, from the one that ties with it): traceback by
     //      pointer into the LDS scratch, then replay forwards in f64 with Primer3's operation order
@@ -403,8 +408,17 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
             const CellBases b = cell_bases(q, (endW >> 4) & 15, endW & 15, cc);
             const double rSn = F.S[b.idxR] + kTiny, rHn = (double)F.H[b.idxR] + kTiny;
             const double Gt = (((double)H + rHn) + K.init_H) - kT37 * ((S + rSn) + K.init_S);
-            if (pass == 0) Gt_1 = Gt;
-            else if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
+            if (pass == 0) {
+                Gt_1 = Gt;
+                if (decisions_only) {   // wave-uniform: a decision that is not close needs no second walk
+                    // what drawDimer() would report for this walk (the totals at the end of this function)
+                    const double G0 = (double)(H + F.H[b.idxR] + 200) -
+                                      (K.temp_k * (((S + F.S[b.idxR]) + K.init_S) + ((P - 1) * K.salt)));
+                    const int ht0 = (H + F.H[b.idxR]) / 10;
+                    second = second & !tied_pick_cannot_conflict(K, G0, P - 1, tieLo - ht0, tieHi - ht0);
+                    any_second = __builtin_amdgcn_ballot_w64(second) != 0ull;
+                }
+            } else if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
                 S = S_1;
                 H = H_1;
                 P = P_1;
@@ -437,6 +451,11 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
             out.r.t = t;
             out.r.conflict = G <= K.g_cut;
         }
+        // a tied terminal pick: resolved above (list mode, one tie), final as "no conflict" when only decisions
+        // are asked for and this one is not close (int_core.hpp kPickMargin), handed on otherwise
+        const bool open_tie = RESOLVE ? (nTie > 1) : (nTie > 0);
+        const int ht = (H + rH) / 10;
+        defer |= (open_tie && !(decisions_only && tied_pick_cannot_conflict(K, G, N, tieLo - ht, tieHi - ht))) ? kDeferPick : 0;
     }
     out.defer = out.r.none ? 0 : defer;
     return out;
@@ -494,7 +513,8 @@ __device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, in
         }
         return;
     }
-    const IntResult r = run_pair_int<NS, RESOLVE, SH>(sh, a.f.c, q, rowmask, n_cells, nmax);
+    const bool decisions_only = a.f.sinks.dg == nullptr && a.f.sinks.tm == nullptr;   // wave-uniform
+    const IntResult r = run_pair_int<NS, RESOLVE, SH>(sh, a.f.c, q, rowmask, n_cells, nmax, decisions_only);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;

@@ -102,7 +102,7 @@ struct SharedRow {
     int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
     // per-lane state that is touched once per cell (registers are the scarce resource: 104 of a lane's
     // 168 hold the table, and what does not fit goes to scratch memory, i.e. to HBM latency)
-    int pick[3][kRowThreads];           // terminal pick: value, word, number of later cells with the same value
+    int pick[3][kRowThreads];           // terminal pick: value, word, 0 or the tied later cells' enthalpy range (max << 16 | min, biased by 32768)
     unsigned soft[2][kRowThreads];      // slots whose value has an equal-valued alternative (bit mask)
     int yts[64];                        // [i][m2]: cell-side mismatch term of an interior loop, G units
     int ytsh[64];                       // ... and its enthalpy / 10
@@ -278,7 +278,8 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  n_cells == 0: idle lane.
 template <int NS>
 __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS,
-                                                  const SeqPair &q, bool active, unsigned wmax4, int n_slots)
+                                                  const SeqPair &q, bool active, unsigned wmax4, int n_slots,
+                                                  bool decisions_only)
 {
     v32i Ga = 0, Wa = kEmptyRowW;
     typename TabTypes<NS>::B Gb = 0, Wb = kEmptyRowW;
@@ -401,7 +402,10 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 sh.pick[1][threadIdx.x] = Wcell;
                 sh.pick[2][threadIdx.x] = 0;
             } else if (in & (Gt == pickG)) {
-                sh.pick[2][threadIdx.x] += 1;
+                // a tie: keep the range of the tied cells' enthalpies (right end included), 16 bits each, biased
+                const unsigned u = (unsigned)min(max(h0 + rh + 32768, 1), 65535), t2 = (unsigned)sh.pick[2][threadIdx.x];
+                const unsigned lo = t2 ? min(t2 & 0xffffu, u) : u, hi = t2 ? max(t2 >> 16, u) : u;
+                sh.pick[2][threadIdx.x] = (int)((hi << 16) | lo);   // never 0: u >= 1
             }
         }
         // ---- publish the cell (idle lanes write a slot nobody reads)
@@ -438,7 +442,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     out.r.conflict = false;
 
     const int nch = (n_slots + kC - 1) / kC;
-    defer |= sh.pick[2][threadIdx.x] > 0 ? kDeferPick : 0;   // a second walk would be paid by the whole wave: handed on
+    const unsigned pick_ties = (unsigned)sh.pick[2][threadIdx.x];   // a second walk would be paid by the whole wave: handed on, unless (below)
     const unsigned long long softTie =
         (unsigned long long)sh.soft[0][threadIdx.x] | ((unsigned long long)sh.soft[1][threadIdx.x] << 32);
 
@@ -513,6 +517,10 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
             out.r.t = t;
             out.r.conflict = G <= K.g_cut;
         }
+        // int_core.hpp kPickMargin: the decision of a pair with a tied pick stands when it is not a close one
+        const int ht = H + rH;   // the walked cell's (H == word_h(endW), or the pair is handed on anyway)
+        const int dh_min = (int)(pick_ties & 0xffffu) - 32768 - ht, dh_max = (int)(pick_ties >> 16) - 32768 - ht;
+        defer |= (pick_ties != 0u && !(decisions_only && tied_pick_cannot_conflict(K, G, N, dh_min, dh_max))) ? kDeferPick : 0;
     }
     out.defer = out.r.none ? 0 : defer;
     return out;
@@ -589,7 +597,8 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
         return;
     }
     const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);
-    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, n_cells > 0, wmax4, n_slots);
+    const bool decisions_only = a.f.sinks.dg == nullptr && a.f.sinks.tm == nullptr;   // wave-uniform
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, n_cells > 0, wmax4, n_slots, decisions_only);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;

@@ -184,6 +184,38 @@ def test_counts_and_bitmap_only_path_medium_pool(eng, m, oracle, oracle_tables):
     assert eng.last_overflow_pairs() > 0      # the overflow stages were exercised
 
 
+@pytest.mark.parametrize("k,kw,thr", [
+    (13, {}, -2500.0), (13, {}, -6000.0), (13, dict(temp_c=60.0, dv=0.0), -500.0),
+    (13, dict(temp_c=37.0, mv=100.0, dv=1.5, dntp=0.2, dna_conc=50.0), -3000.0),
+    (13, dict(temp_c=10.0, mv=1500.0, dv=0.0), -6000.0),      # positive salt term
+    (11, {}, -2000.0), (15, dict(temp_c=45.0), -2500.0), (16, {}, -3500.0)])
+def test_decisions_without_planes_equal_the_exact_planes(eng, m, oracle, oracle_tables, k, kw, thr):
+    """A call without dG / Tm planes lets a pair with a tied terminal pick stand as "no conflict" when no
+    structure of the tie could reach the cut (int_core.hpp kPickMargin: enthalpy range of the tied cells x
+    (1 - T / 310.15), salt term x the pairs a structure can have); with planes every tie is settled exactly.
+    Both calls must flag the same pairs, at thresholds inside the bulk of the dG distribution (a fifth to a
+    half of all pairs conflict, so thousands of ties sit near the cut), for temperatures on both sides of
+    37 C and both signs of the salt term; the planes themselves are compared with the oracle on a sample."""
+    n = 3072
+    pool_ascii = m.synth.random_pool(n, k, seed=1000 + k)
+    pool = m.synth.pool_strings(pool_ascii)
+    chem = m.Chem.ntthal(**kw)
+    exact = eng.cross_dimer(pool, chem, thr, want_dg=True, want_tm=True)
+    eng.pair_stage_stats()
+    fast = eng.cross_dimer(pool, chem, thr, want_dg=False, want_tm=False)
+    np.testing.assert_array_equal(fast["bitmap"], exact["bitmap"])
+    np.testing.assert_array_equal(fast["row_conflicts"], exact["row_conflicts"])
+    frac = float(exact["row_conflicts"].sum()) / (n * n)
+    assert 0.02 < frac < 0.9, frac                      # the cut is inside the distribution
+    # the bitmap of the exact call is its own dG plane cut the reference's way
+    dec = bitmap_to_bool(exact["bitmap"], n)
+    np.testing.assert_array_equal(dec, exact["dg"] <= m.g_cut(thr))
+    # ... and the plane is the oracle's, on a block of rows
+    _, dg, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii, oracle.ntthal_args(**kw), thr, rows=(0, 48))
+    np.testing.assert_array_equal(exact["dg"][:48], dg)
+    np.testing.assert_array_equal(dec[:48], cf.astype(bool))
+
+
 @pytest.mark.parametrize("k,no_split", [(13, False), (21, False), (21, True)])
 def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k, no_split):
     """A rectangular block of the pair matrix (what one rank computes in the multi-GPU tiling); for
