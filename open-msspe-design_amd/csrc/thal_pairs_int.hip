@@ -434,7 +434,8 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         dpath = dpath_1;
         endW = pickW;
     }
-    defer |= dpath;
+    // (a path tie is looked at again below: it only changes the number of pairs of the walked structure)
+    defer |= dpath & ~kDeferPathTie;
     // ---- thal.c drawDimer(): totals
     {
         CellCtx cc;
@@ -456,6 +457,9 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         const bool open_tie = RESOLVE ? (nTie > 1) : (nTie > 0);
         const int ht = (H + rH) / 10;
         defer |= (open_tie && !(decisions_only && tied_pick_cannot_conflict(K, G, N, tieLo - ht, tieHi - ht))) ? kDeferPick : 0;
+        // a cell of the path with an equal-valued alternative of the same enthalpy: the other path gives the same
+        // (dH, dS) with another N, so the same bound with an empty enthalpy range
+        defer |= ((dpath & kDeferPathTie) && !(decisions_only && tied_pick_cannot_conflict(K, G, N, 0, 0))) ? kDeferPathTie : 0;
     }
     out.defer = out.r.none ? 0 : defer;
     return out;

@@ -499,7 +499,8 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     }
     // the replayed enthalpy must be the tracked one; anything else is handed on
     dpath |= (!out.r.none & (H != word_h(endW))) ? kDeferReplay : 0;   // H in units of 10 cal/mol here
-    defer |= dpath;
+    // (a path tie is looked at again below: it only changes the number of pairs of the walked structure)
+    defer |= dpath & ~kDeferPathTie;
     // ---- thal.c drawDimer(): totals
     {
         const KParts pe = k_parts((unsigned)endW >> 17);
@@ -521,6 +522,9 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         const int ht = H + rH;   // the walked cell's (H == word_h(endW), or the pair is handed on anyway)
         const int dh_min = (int)(pick_ties & 0xffffu) - 32768 - ht, dh_max = (int)(pick_ties >> 16) - 32768 - ht;
         defer |= (pick_ties != 0u && !(decisions_only && tied_pick_cannot_conflict(K, G, N, dh_min, dh_max))) ? kDeferPick : 0;
+        // a cell of the path with an equal-valued alternative of the same enthalpy: the other path gives the same
+        // (dH, dS) with another N, so the same bound with an empty enthalpy range
+        defer |= ((dpath & kDeferPathTie) && !(decisions_only && tied_pick_cannot_conflict(K, G, N, 0, 0))) ? kDeferPathTie : 0;
     }
     out.defer = out.r.none ? 0 : defer;
     return out;
