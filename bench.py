@@ -350,6 +350,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # rank 0 is still timing the CPU baseline: the ranks leave together
         dist.destroy_process_group()
     eng.close()
 
