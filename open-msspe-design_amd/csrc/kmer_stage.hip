@@ -113,10 +113,12 @@ __global__ void __launch_bounds__(256) k_pack_rows(const uint8_t *ascii, int n_r
 
 // One thread per (segment, window position).  key = lexicographic-order code of the emitted word
 // (first base in the most significant bits); invalid / duplicate positions get the sentinel.
+// Key = uint32_t when the 2k + 1 key bits fit (k <= 15: a third less sort traffic), uint64_t otherwise.
+template <class Key>
 __global__ void __launch_bounds__(256) k_extract(const SeqView seqs, size_t seq_len, int n_seg,
                                                  int P, int seg_size, int stride, int W, int k,
                                                  int direction, int per, int wins_per_block,
-                                                 uint64_t *key_out, uint32_t *val_out)
+                                                 Key *key_out, uint32_t *val_out)
 {
     extern __shared__ unsigned char smem[];
     uint64_t *fkey = (uint64_t *)smem;                           // [wins_per_block][per] forward keys
@@ -159,11 +161,12 @@ __global__ void __launch_bounds__(256) k_extract(const SeqView seqs, size_t seq_
     bool keep = fk != ~0ull;
     for (int q = 0; keep && q < p; ++q) keep = fkey[w * per + q] != fk;   // first occurrence only
     const size_t inst = (size_t)seg * per + p;
-    key_out[inst] = keep ? word : (1ull << (2 * k));
+    key_out[inst] = (Key)(keep ? word : (1ull << (2 * k)));
     val_out[inst] = (uint32_t)inst;
 }
 
-__global__ void k_heads(const uint64_t *key, size_t n, uint64_t sentinel, uint32_t *head)
+template <class Key>
+__global__ void k_heads(const Key *key, size_t n, uint64_t sentinel, uint32_t *head)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -171,7 +174,8 @@ __global__ void k_heads(const uint64_t *key, size_t n, uint64_t sentinel, uint32
     head[i] = (k != sentinel && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
 }
 
-__global__ void k_index(const uint64_t *key, const uint32_t *val, const uint32_t *head,
+template <class Key>
+__global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *head,
                         const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G,
                         int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys)
 {
@@ -195,7 +199,8 @@ __global__ void k_index(const uint64_t *key, const uint32_t *val, const uint32_t
 }
 
 // lower bound of the sentinel in the sorted key array (single thread, log n steps)
-__global__ void k_tail(const uint64_t *key, size_t n, uint64_t sentinel, uint32_t *post_off, int M)
+template <class Key>
+__global__ void k_tail(const Key *key, size_t n, uint64_t sentinel, uint32_t *post_off, int M)
 {
     size_t lo = 0, hi = n;
     while (lo < hi) {
@@ -964,7 +969,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 128);
     uint32_t *out_freq = (uint32_t *)(out_key + opt.max_iterations);
 
-    // 1. extraction
+    // 1. extraction, 2. inverted index (the key type by the word length)
     const int wins_per_block = std::max(1, 256 / per);
     const int ext_grid = (n_seg + wins_per_block - 1) / wins_per_block;
     const size_t ext_lds = sizeof(uint64_t) * wins_per_block * per + (size_t)wins_per_block * W;
@@ -972,32 +977,41 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         err = "stage A: search window too wide for the extraction kernel";
         return MSSPE_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_extract, dim3(ext_grid), dim3(256), ext_lds, stream, d_seqs, seq_len, n_seg,
-                       (int)P, opt.segment_size, opt.overlap_size, W, k, direction, per,
-                       wins_per_block, key_a, val_a);
-    KM_TRY(hipGetLastError());
-    // 2. inverted index: stable radix sort on the 2k+1 key bits keeps ascending segment order
-    size_t tmp_bytes = 0, tmp2 = 0;
-    KM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a, key_b, val_a, val_b, n_inst, 0u,
-                                     (unsigned)(2 * k + 1), stream));
-    KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
-    if ((rc = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc;
-    KM_TRY(rocprim::radix_sort_pairs(buf_[14], tmp_bytes, key_a, key_b, val_a, val_b, n_inst, 0u,
-                                     (unsigned)(2 * k + 1), stream));
-    const int g_inst = (int)((n_inst + 255) / 256);
-    hipLaunchKernelGGL(k_heads, dim3(g_inst), dim3(256), 0, stream, key_b, n_inst, sentinel, head);
-    KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
-    uint32_t last_head = 0, last_scan = 0;
-    KM_TRY(hipMemcpyAsync(&last_head, head + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
-    KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
-    KM_TRY(hipStreamSynchronize(stream));
-    const int M = (int)(last_head + last_scan);
+    int M = 0;
+    auto build_index = [&](auto key_tag) -> int {
+        using Key = decltype(key_tag);
+        Key *ka = (Key *)key_a, *kb = (Key *)key_b;
+        hipLaunchKernelGGL(k_extract<Key>, dim3(ext_grid), dim3(256), ext_lds, stream, d_seqs, seq_len, n_seg,
+                           (int)P, opt.segment_size, opt.overlap_size, W, k, direction, per,
+                           wins_per_block, ka, val_a);
+        KM_TRY(hipGetLastError());
+        // stable radix sort on the 2k+1 key bits keeps ascending segment order
+        size_t tmp_bytes = 0, tmp2 = 0;
+        KM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u,
+                                         (unsigned)(2 * k + 1), stream));
+        KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
+        int rc2;
+        if ((rc2 = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc2;
+        KM_TRY(rocprim::radix_sort_pairs(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u,
+                                         (unsigned)(2 * k + 1), stream));
+        const int g_inst = (int)((n_inst + 255) / 256);
+        hipLaunchKernelGGL(k_heads<Key>, dim3(g_inst), dim3(256), 0, stream, kb, n_inst, sentinel, head);
+        KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
+        uint32_t last_head = 0, last_scan = 0;
+        KM_TRY(hipMemcpyAsync(&last_head, head + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipStreamSynchronize(stream));
+        M = (int)(last_head + last_scan);
+        if (M == 0) return MSSPE_OK;
+        // number of valid instances = first sentinel position: post_off[M]
+        hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, head, hscan, n_inst,
+                           sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys);
+        // post_off[M] = number of non-sentinel instances (sentinels sort last)
+        hipLaunchKernelGGL(k_tail<Key>, dim3(1), dim3(1), 0, stream, kb, n_inst, sentinel, post_off, M);
+        return MSSPE_OK;
+    };
+    if ((rc = 2 * k + 1 <= 32 ? build_index(uint32_t{}) : build_index(uint64_t{}))) return rc;
     if (M == 0) return MSSPE_OK;
-    // number of valid instances = first sentinel position: post_off[M]
-    hipLaunchKernelGGL(k_index, dim3(g_inst), dim3(256), 0, stream, key_b, val_b, head, hscan, n_inst,
-                       sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys);
-    // post_off[M] = number of non-sentinel instances (sentinels sort last)
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1), 0, stream, key_b, n_inst, sentinel, post_off, M);
     hipLaunchKernelGGL(k_init_counts, dim3((M + 255) / 256), dim3(256), 0, stream, post_off, M, count);
     KM_TRY(hipMemsetAsync(ignored, 0, (size_t)n_seg, stream));
     KM_TRY(hipMemsetAsync(coverage, 0, (size_t)P * 8, stream));

@@ -134,6 +134,14 @@ def test_plain_launches_instead_of_graph_replays(eng, m, oracle, monkeypatch):
         eng.set_option("stage_a_graph", 1)
 
 
+@pytest.mark.parametrize("k", [15, 16, 22, 31])
+def test_long_words_take_the_64_bit_sort_keys(eng, m, oracle, k):
+    """Words of up to 15 bases sort as 32-bit keys (2k + 1 bits), longer ones as 64-bit keys: both sides of
+    the switch and the longest word the packed form holds, against the oracle."""
+    seqs = [bytes(r).decode() for r in m.synth.aligned_genomes(60, 5000)]
+    run_both(eng, m, oracle, seqs, seg=500, stride=250, win=max(50, k + 20), k=k, iters=200, mm=2)
+
+
 def test_candidate_list_loop_equals_the_all_words_loop(eng, m, oracle):
     """The two greedy-loop drivers (option stage_a_candidates: the list of words near the maximum, rebuilt
     whenever the maximum halves, against a scan of every word on every iteration) pick the same winners
