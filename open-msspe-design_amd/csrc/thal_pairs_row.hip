@@ -102,7 +102,8 @@ struct SharedRow {
     int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
     // per-lane state that is touched once per cell (registers are the scarce resource: 104 of a lane's
     // 168 hold the table, and what does not fit goes to scratch memory, i.e. to HBM latency)
-    int pick[3][kRowThreads];           // terminal pick: value, word, 0 or the tied later cells' enthalpy range (max << 16 | min, biased by 32768)
+    int pick[4][kRowThreads];           // terminal pick: value, word, 0 or the tied later cells' enthalpy range (max << 16 | min, biased by
+                                        // 32768), the picked cell's predecessor byte | its "equal-valued alternative" bit << 8
     unsigned soft[2][kRowThreads];      // slots whose value has an equal-valued alternative (bit mask)
     int yts[64];                        // [i][m2]: cell-side mismatch term of an interior loop, G units
     int ytsh[64];                       // ... and its enthalpy / 10
@@ -293,6 +294,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     sh.pick[0][threadIdx.x] = 0x7fffffff;   // pickG
     sh.pick[1][threadIdx.x] = 0;            // pickW
     sh.pick[2][threadIdx.x] = 0;            // nTie
+    sh.pick[3][threadIdx.x] = 0xff;
     sh.soft[0][threadIdx.x] = sh.soft[1][threadIdx.x] = 0u;
 
     // Rows are walked by the WAVE: every lane shares oligo 1, so row i holds the cells whose oligo-2 base
@@ -306,8 +308,11 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
       const int a_row = (int)((q.s1 >> (2 * im1)) & 3u);
       const int w_row = (int)((wmax4 >> (8 * (3 - a_row))) & 0xffu);   // widest lane's cells in this row
       const int row_start = __builtin_amdgcn_readfirstlane(slot_);
+      // The cells of the last row are nobody's predecessors: they are computed and may be picked, but take no
+      // slot (a pair needs cells - cells of the last row slots: three or four more pairs in a hundred fit)
+      const bool stored = im1 < q.len - 1;   // wave-uniform
       unsigned mrem = active ? spaced_mask(q.s2, 3 - a_row, q.lenmask) : 0u;
-      for (int c_ = 0; c_ < w_row; ++c_, ++slot_) {
+      for (int c_ = 0; c_ < w_row; ++c_, slot_ += stored ? 1 : 0) {
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
         // ---- the lane's next complementary cell of this row (none: an empty slot)
         const bool in = mrem != 0u;
@@ -348,7 +353,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         //      of 10 cal/mol (h): T = A / B with A = 10 (h + 20 + rh), 620300 B = 20000 h - G + cq; the
         //      factor 10 drops out of A1 B0 > A0 B1
         // (every LDS read of the cell's own terms is issued here, in one group: one wait, not four)
-        int h0 = sh.h[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
+        int h0 = sh.h[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0, cell_soft = 0;
         const int rh = sh.h[b.idxR], gR = sh.g[b.idxR], hwc = sh.h[b.wc], gwc = sh.g[b.wc];
         const double cq = sh.cq[b.idxR - FastTables::kEndR];
         const int pickG = sh.pick[0][threadIdx.x];
@@ -381,6 +386,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 G0 = best.G;
                 pred = word_cw(best.W);
             } else if (hw == h0) {
+                cell_soft = 0x100;
                 if (in) sh.soft[slot >> 5][threadIdx.x] |= 1u << (slot & 31);
             } else {
                 flags |= kDeferLoopEq;
@@ -401,6 +407,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 sh.pick[0][threadIdx.x] = Gt;
                 sh.pick[1][threadIdx.x] = Wcell;
                 sh.pick[2][threadIdx.x] = 0;
+                sh.pick[3][threadIdx.x] = pred | cell_soft;
             } else if (in & (Gt == pickG)) {
                 // a tie: keep the range of the tied cells' enthalpies (right end included), 16 bits each, biased
                 const unsigned u = (unsigned)min(max(h0 + rh + 32768, 1), 65535), t2 = (unsigned)sh.pick[2][threadIdx.x];
@@ -409,6 +416,8 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
             }
         }
         // ---- publish the cell (idle lanes write a slot nobody reads)
+        // (the cells of the last row all land in the first free slot, which the sizing keeps free: nothing
+        //  reads it -- no row follows, and the walk back only matches predecessors)
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0;
             Wa[slot & 31] = Wcell;
@@ -452,8 +461,15 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
     int H = 0, P = 0, dpath = 0;
     const int endW = sh.pick[1][threadIdx.x];
     {
-        unsigned cur = word_sig(endW);
-        bool done = out.r.none;
+        // the picked cell (which may have no slot) opens the path; the walk goes on from its predecessor
+        const int end3 = sh.pick[3][threadIdx.x];
+        unsigned cur = sig_of_cw(end3 & 0xff);
+        bool done = out.r.none | ((end3 & 0xff) == 0xff);
+        if (!out.r.none) {
+            sh.path[0][threadIdx.x] = (unsigned short)((unsigned)endW >> 17);
+            P = 1;
+            dpath |= (end3 & 0x100) ? kDeferPathTie : 0;
+        }
         for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
             const int pc = __builtin_amdgcn_readfirstlane(pc_);
             int W[kC];
@@ -541,59 +557,69 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     // (values read from the LDS copy of the arguments are vector registers: what steers control flow is
     // made a scalar again, or every loop over it becomes a divergent one)
     const int k = __builtin_amdgcn_readfirstlane(a.f.k);
-    int n_cells = setup_pair(pa, pb, k, q, rowmask);
+    const int n_all = setup_pair(pa, pb, k, q, rowmask);
     q.s1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.s1);   // the block's row primer: a scalar
     q.len = k;
     q.lenmask = (unsigned)__builtin_amdgcn_readfirstlane((int)q.lenmask);
+    const unsigned lenmask = q.lenmask;
+    // A pair's table holds its complementary cells except those of the last row (run_pair_row): n_cells below
+    // is that number, the quantity every sizing decision is about.
+    int c2[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c2[b] = __popc(spaced_mask(q.s2, b, lenmask));
+    const int last_base = (int)((q.s1 >> (2 * (k - 1))) & 3u);   // scalar
+    int n_cells = n_all - c2[3 - last_base];
     const bool sym = self_complementary(pa, k) && self_complementary(pb, k);
-    bool spill = inside & ((n_cells > NS) | sym);
+    constexpr int kFit = NS - 1;   // one slot stays free: the cells of the last row are written there
+    bool spill = inside & ((n_cells > kFit) | sym);
     unsigned flag = 0u;
-    if (!inside | spill) n_cells = 0;
+    bool active = inside & !spill & (n_all > 0);   // lanes that run the DP
+    if (!active) n_cells = 0;
     int nmax = wave_max_u8(n_cells);
     // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes far above
     // the rest (mixed compositions at bin boundaries) are cheaper in a sorted list stage.
     for (int round = 0; round < 6; ++round) {
         const int next = wave_max_u8(n_cells < nmax ? n_cells : 0);
-        const int m = __popcll(__ballot(n_cells == nmax));
+        const int m = __popcll(__ballot(active && n_cells == nmax));
         if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform
-        if (n_cells == nmax) {
+        if (active && n_cells == nmax) {
             spill = true;
+            active = false;
             n_cells = 0;
         }
         nmax = next;
     }
-    // Slots the wave needs: row i takes the widest lane's count of base 3 - s1[i].  If that is more than
-    // the table holds, the lanes with the most cells leave for the list stage until it fits.
-    const unsigned lenmask = q.lenmask;
-    int c2[4], w4[4] = {0, 0, 0, 0}, n_slots = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) c2[b] = __popc(spaced_mask(q.s2, b, lenmask));
+    // Slots the wave needs: row i (but the last) takes the widest lane's count of base 3 - s1[i].  If that is
+    // more than the table holds, the lanes with the most cells leave for the list stage until it fits.
+    const unsigned rowsmask = lenmask >> 2;   // rows 0 .. k - 2
+    int w4[4] = {0, 0, 0, 0}, n_slots = 0;
     for (;;) {
-        if (nmax == 0) break;   // wave-uniform
+        if (__ballot(active) == 0ull) break;   // wave-uniform
         n_slots = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            w4[b] = wave_max_u8(n_cells > 0 ? c2[b] : 0);
-            n_slots += w4[b] * __popc(spaced_mask(q.s1, 3 - b, lenmask));   // rows whose cells have base b on oligo 2
+            w4[b] = wave_max_u8(active ? c2[b] : 0);
+            n_slots += w4[b] * __popc(spaced_mask(q.s1, 3 - b, rowsmask));   // stored rows whose cells have base b on oligo 2
         }
-        if (n_slots <= NS) break;
+        if (n_slots <= kFit) break;
         // Too many slots: the wave mixes compositions (it straddles a bin boundary, or the pool is small).
         // Keep the larger party: lanes with the composition of the first active lane stay if they are at
         // least half of the active lanes, else they are the ones to go.  (Lanes of one composition need
         // exactly their own cell count, which fits: larger tables left above.)
         const unsigned sig = (unsigned)c2[0] | ((unsigned)c2[1] << 8) | ((unsigned)c2[2] << 16) | ((unsigned)c2[3] << 24);
-        const unsigned long long act = __ballot(n_cells > 0);
+        const unsigned long long act = __ballot(active);
         const unsigned sig0 = (unsigned)__shfl((int)sig, __ffsll((long long)act) - 1);
-        const unsigned long long same = __ballot(n_cells > 0 && sig == sig0);
+        const unsigned long long same = __ballot(active && sig == sig0);
         const bool keep_same = 2 * __popcll(same) >= __popcll(act);
         const bool uniform = same == act;   // cannot happen with n_slots > NS; never loop on it
-        if (n_cells > 0 && (uniform ? n_cells == nmax : ((sig == sig0) != keep_same))) {
+        if (active && (uniform ? n_cells == nmax : ((sig == sig0) != keep_same))) {
             spill = true;
+            active = false;
             n_cells = 0;
         }
         nmax = wave_max_u8(n_cells);
     }
-    if (nmax == 0) {   // wave-uniform: nothing to compute
+    if (__ballot(active) == 0ull) {   // wave-uniform: nothing to compute
         if (spill) {
             const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
             if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
@@ -602,7 +628,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     }
     const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);
     const bool decisions_only = a.f.sinks.dg == nullptr && a.f.sinks.tm == nullptr;   // wave-uniform
-    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, n_cells > 0, wmax4, n_slots, decisions_only);
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, active, wmax4, n_slots, decisions_only);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;
