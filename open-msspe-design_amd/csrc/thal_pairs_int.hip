@@ -192,6 +192,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
     // below row_lo2 lies at least three rows above the current cell
     int row_lo0 = 0, row_lo1 = 0, row_lo2 = 0;
     int pickG = 0x7fffffff, pickW = 0, pickW2 = 0, nTie = 0, tieLo = 0, tieHi = 0;
+    int pickP = 0xff, pickP2 = 0xff;   // the picked cells' predecessor byte | "has an equal-valued alternative" << 8
     unsigned long long softTie = 0ull;   // per lane: slots whose value has an equal-valued alternative
 
     for (int slot_ = 0; slot_ < nmax; ++slot_) {
@@ -235,7 +236,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         // ---- thal.c maxTM(): helix extension if it raises Tm.  T = A / B with B < 0 on both
         //      sides, so T1 > T0 <=> A1 B0 > A0 B1; 620300 B = (2000 H - G) + cq (exact integers
         //      plus one constant: decisive unless the two sides agree to 1e-9).
-        int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0;
+        int H0 = F.H[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0, cell_soft = 0;
         if (stHave) {
             const int rH = F.H[b.idxR];
             const double cq = sh.cq[b.idxR - FastTables::kEndR];
@@ -268,7 +269,8 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
                 pred = best.W & 0xff;
             } else if (Hw == H0) {
                 // same value either way: only the path (and the rounding along it) could differ
-                softTie |= (slot < n_cells) ? (1ull << slot) : 0ull;
+                cell_soft = 0x100;
+                softTie |= ((slot < n_cells) & (slot < 64)) ? (1ull << (slot & 63)) : 0ull;
             } else {
                 flags |= kDeferLoopEq;
             }
@@ -283,6 +285,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
             const int Gt = G0 + sh.g[b.idxR];
             const bool pick = in & (Gt < pickG);
             const bool same = in & (Gt == pickG);
+            pickP2 = (same & (nTie == 0)) ? (pred | cell_soft) : pickP2;
             pickW2 = (same & (nTie == 0)) ? Wcell : pickW2;   // the first later cell with the same value
             {   // range of the tied later cells' enthalpies (right end included, units of 10 cal/mol)
                 const int ht = (H0 + F.H[b.idxR]) / 10;   // both multiples of 10 (build_int_tables)
@@ -292,35 +295,39 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
             nTie = pick ? 0 : (nTie + (same ? 1 : 0));
             pickG = pick ? Gt : pickG;
             pickW = pick ? Wcell : pickW;
+            pickP = pick ? (pred | cell_soft) : pickP;
         }
-        // ---- publish the cell (idle lanes write a slot nobody reads)
-        if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
-            Ga[slot & 31] = G0;
-            Wa[slot & 31] = Wcell;
+        // ---- publish the cell (idle lanes write a slot nobody reads).  From slot NS - 1 on every lane still
+        //      at work is in its last row (wave_pairs), whose cells are nobody's predecessors: they all land in
+        //      slot NS - 1, which nothing reads
+        const int ps = min(slot, NS - 1);   // wave-uniform; slot NS - 1 is kept free for them (wave_pairs)
+        if (ps < 32) {   // wave-uniform slot number: one indexed register write per plane
+            Ga[ps & 31] = G0;
+            Wa[ps & 31] = Wcell;
         } else if constexpr (NS == 56) {
-            if (slot < 48) {
-                Gb[(slot - 32) & 15] = G0;
-                Wb[(slot - 32) & 15] = Wcell;
+            if (ps < 48) {
+                Gb[(ps - 32) & 15] = G0;
+                Wb[(ps - 32) & 15] = Wcell;
             } else {
-                Gc[(slot - 48) & 7] = G0;
-                Wc[(slot - 48) & 7] = Wcell;
+                Gc[(ps - 48) & 7] = G0;
+                Wc[(ps - 48) & 7] = Wcell;
             }
         } else if constexpr (NS == 48) {
-            Gb[(slot - 32) & 15] = G0;
-            Wb[(slot - 32) & 15] = Wcell;
+            Gb[(ps - 32) & 15] = G0;
+            Wb[(ps - 32) & 15] = Wcell;
         } else if constexpr (NS == 52) {
-            if (slot < 48) {
-                Gb[(slot - 32) & 15] = G0;
-                Wb[(slot - 32) & 15] = Wcell;
+            if (ps < 48) {
+                Gb[(ps - 32) & 15] = G0;
+                Wb[(ps - 32) & 15] = Wcell;
             } else {
-                Gc[(slot - 48) & 3] = G0;
-                Wc[(slot - 48) & 3] = Wcell;
+                Gc[(ps - 48) & 3] = G0;
+                Wc[(ps - 48) & 3] = Wcell;
             }
         } else {
-            Gb[(slot - 32) & 31] = G0;
-            Wb[(slot - 32) & 31] = Wcell;
+            Gb[(ps - 32) & 31] = G0;
+            Wb[(ps - 32) & 31] = Wcell;
         }
-        sh.pred[slot][threadIdx.x] = (unsigned char)pred;
+        sh.pred[ps][threadIdx.x] = (unsigned char)pred;
     }
 
     IntResult out;
@@ -329,7 +336,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
     out.r.t = 0.0;
     out.r.conflict = false;
 
-    const int nch = (nmax + kC - 1) / kC;
+    const int nch = (min(nmax, NS) + kC - 1) / kC;
     // (kDeferPick is decided at the end: int_core.hpp kPickMargin)
     bool second = RESOLVE && !out.r.none && nTie == 1;
     bool any_second = RESOLVE && __builtin_amdgcn_ballot_w64(second) != 0ull;   // wave-uniform
@@ -352,8 +359,16 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         P = 0;
         dpath = 0;
         {
-            int cur = endW & 0xff;
-            bool done = out.r.none | ((pass == 1) & !second);
+            // the picked cell (which may have no slot) opens the path; the walk goes on from its predecessor
+            const int endP = pass == 0 ? pickP : pickP2;
+            const bool walk = !(out.r.none | ((pass == 1) & !second));
+            int cur = endP & 0xff;
+            bool done = !walk | (cur == 0xff);
+            if (walk) {
+                sh.path[0][threadIdx.x] = (unsigned short)(core_word(endW) & 0x3fff);
+                P = 1;
+                dpath |= (endP & 0x100) ? kDeferPathTie : 0;
+            }
             for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
                 const int pc = __builtin_amdgcn_readfirstlane(pc_);
                 int W[kC];
@@ -363,9 +378,9 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
                 for (int e = kC - 1; e >= 0; --e) {
                     const int slot = pc * kC + e;
                     const int pr = sh.pred[slot][threadIdx.x];
-                    const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);
+                    const bool hit = !done & (slot < n_cells) & ((W[e] & 0xff) == cur);   // predecessors only: cur is never the end cell
                     if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)(core_word(W[e]) & 0x3fff);
-                    dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
+                    dpath |= (hit & (((softTie >> (slot & 63)) & 1ull) != 0ull)) ? kDeferPathTie : 0;
                     P += hit ? 1 : 0;
                     cur = hit ? pr : cur;
                     done = done | (hit & (pr == 0xff));
@@ -493,7 +508,9 @@ __device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, in
     unsigned rowmask;
     int n_cells = setup_pair(pa, pb, a.f.k, q, rowmask);
     const bool sym = self_complementary(pa, a.f.k) && self_complementary(pb, a.f.k);
-    bool spill = inside & (pass_on | (n_cells > NS) | sym);
+    // the cells of the lane's last row (the last ones of its row-major order) take no slot: run_pair_int
+    const int last_row = __popc(spaced_mask(q.s2, 3 - (int)((q.s1 >> (2 * (a.f.k - 1))) & 3u), q.lenmask));
+    bool spill = inside & (pass_on | (n_cells - last_row > NS - 1) | sym);   // one slot stays free for the last row's writes
     unsigned flag = pass_on ? pass_flag : 0u;
     if (!inside | spill) n_cells = 0;
     int nmax = wave_max_u8(n_cells);
