@@ -142,6 +142,20 @@ def test_long_words_take_the_64_bit_sort_keys(eng, m, oracle, k):
     run_both(eng, m, oracle, seqs, seg=500, stride=250, win=max(50, k + 20), k=k, iters=200, mm=2)
 
 
+def test_many_partitions_take_the_all_words_loop(eng, m, oracle):
+    """More partitions than the candidate-list kernel keeps bitmaps for (8,192): the loop runs the all-words
+    batches; same winners as the oracle."""
+    rng = np.random.default_rng(3)
+    anc = rng.integers(0, 4, 172000)
+    seqs = []
+    for r in range(3):
+        row = anc.copy()
+        mut = rng.random(anc.size) < 0.02
+        row[mut] = rng.integers(0, 4, int(mut.sum()))
+        seqs.append("".join("ACGT"[x] for x in row))
+    run_both(eng, m, oracle, seqs, seg=40, stride=20, win=20, k=6, iters=120, mm=1)   # 8,599 partitions
+
+
 def test_candidate_list_loop_equals_the_all_words_loop(eng, m, oracle):
     """The two greedy-loop drivers (option stage_a_candidates: the list of words near the maximum, rebuilt
     whenever the maximum halves, against a scan of every word on every iteration) pick the same winners
