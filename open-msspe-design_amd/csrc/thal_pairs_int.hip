@@ -168,10 +168,13 @@ __device__ __forceinline__ void scan_fill_int(MSSPE_TAB_PARAMS, int upto, int fa
 }
 
 
-// thal ANY for the lane's pair.  n_cells == 0: idle lane.
+// thal ANY for the lane's pair.  n_cells == 0: idle lane.  n_cells counts every complementary cell; the
+// lane's last-row cells (the last ones of its row-major order) may lie beyond slot NS - 1: they are computed
+// and may be picked, but only cells of earlier rows are ever read back (wave_pairs sizes the table by them).
 // RESOLVE: a terminal pick shared by exactly two cells is settled the way Primer3 settles it, by
 // replaying both paths and comparing the two doubles (list mode; in matrix mode such pairs are
-// handed on, because a second walk would be paid by the whole wave).
+// handed on, because a second walk would be paid by the whole wave) -- unless the call asks for
+// decisions only and no tied structure can reach the cut (int_core.hpp kPickMargin).
 template <int NS, bool RESOLVE, class SH>
 __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, const SeqPair &q,
                                                   unsigned rowmask, int n_cells, int nmax, bool decisions_only)

@@ -276,7 +276,8 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
     }
 }
 
-// thal ANY for the lane's pair (oligo 1 = the block's row primer).  n_cells == 0: idle lane.
+// thal ANY for the lane's pair (oligo 1 = the block's row primer).  !active: idle lane.  n_slots: the slots the
+// wave's rows take (all rows but the last, padded to the widest lane); wmax4: the widest lane's count of each base.
 template <int NS>
 __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS,
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
