@@ -46,9 +46,12 @@ struct ChemEntry {
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
 constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows with the call up to kListCapMax): one launch can never overrun it
-constexpr long kListCapMax = 1L << 28;       // 2 GB per list (two of them): the stages behind the first run every two launches
-                                             // of 2^27 pairs, so that a list cannot be overrun even if every pair were handed on
-                                             // (6 % are); k_accumulate_overflow checks the counters against it all the same
+constexpr long kListCapMax = 1L << 30;       // 8 GB per list (two of them, 6 % of the card's memory): the stages behind the first
+                                             // run every eight launches of 2^27 pairs, so that a list cannot be overrun even if
+                                             // every pair were handed on (2.7 % are); k_accumulate_overflow checks the counters
+                                             // against it all the same.  The kernels of a flush are mostly latency (a one-wave-
+                                             // per-pair launch of 1.5 ms for a handful of pairs): 2^28 -> 2^30 is 17 -> 5 flushes
+                                             // per 65,536^2 screen and 1.5 % of its time
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace

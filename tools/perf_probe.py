@@ -19,6 +19,9 @@ def main():
         from msspe_amd import capi
         capi.use_library(os.environ["MSSPE_PROBE_LIB"])
     eng = m.Engine(0)
+    for kv in os.environ.get("MSSPE_PROBE_OPTIONS", "").split(","):
+        if kv:
+            eng.set_option(*kv.split("="))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     chem = m.Chem.ntthal()
     for n in sizes:
