@@ -49,9 +49,8 @@ constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows wi
 constexpr long kListCapMax = 1L << 30;       // 8 GB per list (two of them, 6 % of the card's memory): the stages behind the first
                                              // run every eight launches of 2^27 pairs, so that a list cannot be overrun even if
                                              // every pair were handed on (2.7 % are); k_accumulate_overflow checks the counters
-                                             // against it all the same.  The kernels of a flush are mostly latency (a one-wave-
-                                             // per-pair launch of 1.5 ms for a handful of pairs): 2^28 -> 2^30 is 17 -> 5 flushes
-                                             // per 65,536^2 screen and 1.5 % of its time
+                                             // against it all the same.  The small kernels of a flush do not fill the card:
+                                             // 2^28 -> 2^30 is 17 -> 5 flushes per 65,536^2 screen and 1.5 % of its time
 constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' workspace
 
 }  // namespace
