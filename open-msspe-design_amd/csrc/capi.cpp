@@ -81,6 +81,7 @@ struct msspe_ctx {
     uint2 *ovf_list2 = nullptr;        // pairs the wide kernel could not hold either
     uint32_t *ovf_count = nullptr;     // list counters of the stages (8): [0] first, [1] second, ...
     long list_cap = 0;                 // entries per hand-over list
+    long list_cap_ceiling = 1L << 30;  // lowered when an allocation of that size failed (not tried again)
     uint64_t *d_ovf_total = nullptr;   // [0] pairs handed on so far, [1] != 0: a list counter went past its capacity
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
@@ -208,7 +209,7 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_reasons, 0, (9 + 1024 + 8) * sizeof(unsigned long long), ctx->stream));
     }
     long want = kListCapMin;
-    while (want < total_pairs && want < kListCapMax) want <<= 1;
+    while (want < total_pairs && want < kListCapMax && want < ctx->list_cap_ceiling) want <<= 1;
     const bool fixed = ctx->opt.list_cap_log2 >= 20 && ctx->opt.list_cap_log2 <= 30;
     if (fixed) want = 1L << ctx->opt.list_cap_log2;
     if (ctx->ovf_list && ctx->ovf_list2 && (ctx->list_cap == want || (ctx->list_cap > want && !fixed))) return MSSPE_OK;
@@ -219,14 +220,22 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
         ctx->ovf_list = ctx->ovf_list2 = nullptr;
         ctx->list_cap = 0;
     }
-    hipError_t e1 = hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want);
-    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want) : e1;
-    if (e1 != hipSuccess || e2 != hipSuccess) {   // all or nothing: a later call starts from a clean state
+    // The large sizes only buy fewer flushes: when the card is short of memory (the caller's own tensors), a
+    // smaller pair of lists does, down to what one launch can fill.
+    const long floor_cap = std::max(kListCapMin, std::min(want, kChunkPairs));
+    for (;;) {
+        hipError_t e1 = hipMalloc((void **)&ctx->ovf_list, sizeof(uint2) * (size_t)want);
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&ctx->ovf_list2, sizeof(uint2) * (size_t)want) : e1;
+        if (e1 == hipSuccess && e2 == hipSuccess) break;
+        // all or nothing: a later call starts from a clean state
         if (ctx->ovf_list) (void)hipFree(ctx->ovf_list);
         if (ctx->ovf_list2) (void)hipFree(ctx->ovf_list2);
         ctx->ovf_list = ctx->ovf_list2 = nullptr;
         ctx->list_cap = 0;
-        return hip_fail(ctx, e1 != hipSuccess ? e1 : e2, "hipMalloc(hand-over lists)");
+        (void)hipGetLastError();
+        if (fixed || want <= floor_cap) return hip_fail(ctx, e1 != hipSuccess ? e1 : e2, "hipMalloc(hand-over lists)");
+        want >>= 1;
+        ctx->list_cap_ceiling = want;
     }
     ctx->list_cap = want;
     return MSSPE_OK;

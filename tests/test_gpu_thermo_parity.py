@@ -216,6 +216,35 @@ def test_decisions_without_planes_equal_the_exact_planes(eng, m, oracle, oracle_
     np.testing.assert_array_equal(dec[:48], cf.astype(bool))
 
 
+def test_hand_over_lists_shrink_when_the_card_is_full(m):
+    """A 32,768-primer screen (2^30 pairs) asks for two hand-over lists of 8 GB; with only 10 GB left on the
+    card the engine takes smaller lists (more flushes) and the screen comes out the same."""
+    import torch
+    n = 32768
+    pool_ascii = m.synth.random_pool(n, 13, seed=909)
+    d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
+    counts = []
+    for squeeze in (False, True):
+        eng = m.Engine(0)
+        d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+        hog = None
+        try:
+            if squeeze:
+                torch.cuda.empty_cache()
+                free, _ = torch.cuda.mem_get_info()
+                hog = torch.empty(max(free - (10 << 30), 0), dtype=torch.uint8, device="cuda")
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, 13, m.Chem.ntthal(), -9000.0, (0, n), (0, n), d_rc.data_ptr())
+            eng.synchronize()
+            counts.append(d_rc.cpu().numpy().copy())
+            assert eng.last_overflow_pairs() > 0
+        finally:
+            del hog
+            eng.close()
+            torch.cuda.empty_cache()
+    np.testing.assert_array_equal(counts[0], counts[1])
+    assert int(counts[0].sum()) > 0
+
+
 @pytest.mark.parametrize("k,no_split", [(13, False), (21, False), (21, True)])
 def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k, no_split):
     """A rectangular block of the pair matrix (what one rank computes in the multi-GPU tiling); for
