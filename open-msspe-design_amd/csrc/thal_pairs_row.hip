@@ -625,6 +625,13 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
             const uint32_t at = atomicAdd(a.f.ovf_count, 1u);
             if (at < a.f.ovf_cap) a.f.ovf_list[at] = make_uint2((unsigned)row | flag, (unsigned)col);
         }
+        // lanes inside the block that are not handed on have no complementary cell at all: thal() finds no
+        // structure (dG = inf, t = 0, no conflict) -- the planes are the caller's memory and must say so
+        if (inside & !spill) {
+            const size_t orow = (size_t)(row - a.f.sinks.row0), ocol = (size_t)(col - a.f.sinks.col0);
+            if (a.f.sinks.dg) a.f.sinks.dg[orow * (size_t)a.f.sinks.ncols + ocol] = INFINITY;
+            if (a.f.sinks.tm) a.f.sinks.tm[orow * (size_t)a.f.sinks.ncols + ocol] = 0.0;
+        }
         return;
     }
     const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);

@@ -216,6 +216,27 @@ def test_decisions_without_planes_equal_the_exact_planes(eng, m, oracle, oracle_
     np.testing.assert_array_equal(dec[:48], cf.astype(bool))
 
 
+@pytest.mark.parametrize("k,pair_kernel", [(9, "auto"), (13, "auto"), (13, "int"), (13, "f64"), (15, "auto")])
+def test_pairs_without_a_complementary_cell(eng, m, oracle, oracle_tables, k, pair_kernel):
+    """Two-letter pools (T/C against T/C, A/G against A/G): whole waves in which no pair has a single
+    complementary cell.  thal() finds no structure there (dG = inf, t = 0) and the planes must say so -- the
+    integer kernels used to leave such a wave's plane entries unwritten (found by a randomised campaign with
+    skewed compositions; decisions and counts were never affected)."""
+    rng = np.random.default_rng(31 + k)
+    tc = np.frombuffer(b"TC", dtype=np.uint8)[rng.integers(0, 2, (160, k))]
+    ag = np.frombuffer(b"AG", dtype=np.uint8)[rng.integers(0, 2, (130, k))]
+    mixed = m.synth.random_pool(60, k, seed=5)
+    skew = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.choice(4, size=(150, k), p=[0.05, 0.45, 0.05, 0.45])]
+    pool = m.synth.pool_strings(np.concatenate([tc, ag, mixed, skew]))
+    eng.set_option("pair_kernel", pair_kernel)
+    try:
+        out, cnt = check_pool(eng, m, oracle, oracle_tables, pool)
+    finally:
+        eng.set_option("pair_kernel", "auto")
+    assert np.isinf(out["dg"][:160, :160]).all() and np.isinf(out["dg"][160:290, 160:290]).all()
+    assert cnt > 0
+
+
 def test_hand_over_lists_shrink_when_the_card_is_full(m):
     """A 32,768-primer screen (2^30 pairs) asks for two hand-over lists of 8 GB; with only 10 GB left on the
     card the engine takes smaller lists (more flushes) and the screen comes out the same."""
