@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential campaign (development aid, GPU): pools of random length, size, chemistry, threshold
 and -- every third case -- skewed base composition (large tables, pairs without a complementary cell, many ties)
-through the exact-planes call and the decision-only call, against the oracle.  usage: random_campaign.py [seed] [cases]"""
+through the exact-planes call and the decision-only call, against the oracle.  usage: random_campaign.py [seed] [cases] [k_lo] [k_hi]"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -11,10 +11,12 @@ import msspe_amd as m, pyoracle as o
 eng = m.Engine(0); tabs = o.Tables()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 77)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+klo = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+khi = int(sys.argv[4]) if len(sys.argv) > 4 else 16
 bad = 0
 for it in range(cases):
-    k = int(rng.integers(9, 17))
-    n = int(rng.integers(1200, 2600))
+    k = int(rng.integers(klo, khi + 1))
+    n = int(rng.integers(1200, 2600) if k <= 16 else rng.integers(300, 700))
     kw = [{}, dict(temp_c=37.0), dict(temp_c=55.0, dv=0.0), dict(mv=200.0, dv=0.5, dntp=0.2), dict(temp_c=15.0, mv=1200.0, dv=0.0)][int(rng.integers(0, 5))]
     thr = float(rng.choice([-9000.0, -6000.0, -3500.0, -1500.0]))
     seed = int(rng.integers(1, 1 << 30))
