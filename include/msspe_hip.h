@@ -112,6 +112,9 @@ void msspe_unpack_oligo(uint64_t packed, int k, char *ascii_out /* k+1 bytes */)
  *                  +inf where thal finds no structure (ntthal prints nothing for such a pair;
  *                  this engine defines "no edge")
  *   tm             double[...] melting temperature t (Celsius), 0 where no structure
+ * A call without the dg / tm planes asks for decisions only: where thal()'s terminal pick is a tie that doubles
+ * would settle by rounding, such a call may let the pair stand as "no conflict" without settling it, if no
+ * structure of the tie can reach the cut.  The bits, counts and edges are the same either way.
  */
 int msspe_cross_dimer_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
                           const msspe_chem *chem, float dg_threshold,
