@@ -69,6 +69,8 @@ constexpr int kRowA = 772;                       // stride of l2: 4 * 14 * 13 = 
 constexpr int kRowTEntries = kRowL2 * kRowA;
 constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
 constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
+constexpr int kRowGBase = FastTables::kTSc;      // first compact-table entry kept in LDS
+constexpr int kRowGCount = FastTables::kCount - kRowGBase;
 constexpr int kNoY = 1 << 28;                    // table entries at or above kNoY / 2 carry this offset: no cell-side term
 // The running minimum of a scan is ONE v_min_f64 on the pair (candidate value : slot word): every vector
 // instruction of this loop issues at the same rate, f64 or not, and a minimum of two 64-bit
@@ -107,8 +109,10 @@ struct SharedRow {
     unsigned soft[2][kRowThreads];      // slots whose value has an equal-valued alternative (bit mask)
     int yts[64];                        // [i][m2]: cell-side mismatch term of an interior loop, G units
     int ytsh[64];                       // ... and its enthalpy / 10
-    int g[FastTables::kCount];
-    int h[FastTables::kCount];          // enthalpy / 10 per compact-table entry (every finite one is a multiple of 10 cal/mol)
+    // the entries of the compact tables that a cell reads (cell-side mismatch, end and stacked-pair terms:
+    // FastTables::kTSc and up); the loop entries below that are read once per step of the replay, from global
+    int g[kRowGCount];
+    int h[kRowGCount];                  // enthalpy / 10 (every finite one is a multiple of 10 cal/mol)
     short TH[kRowTEntries + 4];         // enthalpy / 10 of the loop term T holds, << 1 | "the lane adds ytsh" (same index)
     double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
     unsigned char pred[kRowSlots][kRowThreads];
@@ -279,7 +283,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  !active: idle lane.  n_slots: the slots the
 // wave's rows take (all rows but the last, padded to the widest lane); wmax4: the widest lane's count of each base.
 template <int NS>
-__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS,
+__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS, const int *gH,
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
                                                   bool decisions_only)
 {
@@ -354,8 +358,8 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         //      of 10 cal/mol (h): T = A / B with A = 10 (h + 20 + rh), 620300 B = 20000 h - G + cq; the
         //      factor 10 drops out of A1 B0 > A0 B1
         // (every LDS read of the cell's own terms is issued here, in one group: one wait, not four)
-        int h0 = sh.h[b.idxL], G0 = sh.g[b.idxL], pred = 0xff, flags = 0, cell_soft = 0;
-        const int rh = sh.h[b.idxR], gR = sh.g[b.idxR], hwc = sh.h[b.wc], gwc = sh.g[b.wc];
+        int h0 = sh.h[b.idxL - kRowGBase], G0 = sh.g[b.idxL - kRowGBase], pred = 0xff, flags = 0, cell_soft = 0;
+        const int rh = sh.h[b.idxR - kRowGBase], gR = sh.g[b.idxR - kRowGBase], hwc = sh.h[b.wc - kRowGBase], gwc = sh.g[b.wc - kRowGBase];
         const double cq = sh.cq[b.idxR - FastTables::kEndR];
         const int pickG = sh.pick[0][threadIdx.x];
         if (stHave && !(MSSPE_KO & 4)) {
@@ -501,14 +505,14 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 const CellBases b = cell_bases(q, (core >> 4) & 15, core & 15, cc);
                 if (step == 0) {
                     S = gS[b.idxL];
-                    H = sh.h[b.idxL];
+                    H = sh.h[b.idxL - kRowGBase];
                 } else if (((core & 0xff) - (prevCore & 0xff)) == 0x11) {   // the cell (i-1, j-1): stacked pair
                     S = S + gS[b.wc];
-                    H = H + sh.h[b.wc];
+                    H = H + sh.h[b.wc - kRowGBase];
                 } else {
                     const CandGeom g = cand_geometry(cc, prevCore);
                     S = ((gS[g.lx] + gS[g.y]) + gS[g.zi]) + S;   // thal.c's order (pair_core.hpp cand_finish)
-                    H = sh.h[g.lx] + sh.h[g.y] + H;
+                    H = gH[g.lx] / 10 + sh.h[g.y - kRowGBase] + H;   // the loop entry from global, like its entropy
                 }
                 prevCore = core;
             }
@@ -524,7 +528,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         CellCtx cc;
         const CellBases b = cell_bases(q, pe.ii, pe.jj, cc);
         const double rS = gS[b.idxR];
-        const int rH = sh.h[b.idxR];
+        const int rH = sh.h[b.idxR - kRowGBase];
         const double dH = (double)((H + rH) * 10 + 200);
         const double dS = (S + rS) + K.init_S;
         const int N = P - 1;
@@ -636,7 +640,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     }
     const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);
     const bool decisions_only = a.f.sinks.dg == nullptr && a.f.sinks.tm == nullptr;   // wave-uniform
-    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, q, active, wmax4, n_slots, decisions_only);
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, a.f.ft->H, q, active, wmax4, n_slots, decisions_only);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;
@@ -715,9 +719,9 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
                     const int m1 = (int)((s1 >> (2 * i - 2)) & 3u);
                     const int ci = ((3 - a_c) * 4 + n2) * 4 + m1;
                     const int ye = (d == 0x11 ? FastTables::kMMc : FastTables::kTSc) + ci;
-                    const int y = sh.g[ye];
+                    const int y = sh.g[ye - kRowGBase];
                     v = (v >= IntTables::kValid || y >= IntTables::kValid) ? IntTables::kBig : v + y;
-                    hv += sh.h[ye] * 10;
+                    hv += sh.h[ye - kRowGBase] * 10;
                 } else {
                     needs_y = v < IntTables::kValid;
                 }
@@ -736,10 +740,10 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
         const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
         const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
         {
-            const int y = sh.g[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+            const int y = sh.g[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
             sh.yts[threadIdx.x] = y >= IntTables::kValid ? kRowU : y;   // void stays void, and in range (kRowD)
         }
-        sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc + (((3 - a_c) * 4 + m2) * 4 + m1)];
+        sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
     }
 }
 
@@ -747,9 +751,9 @@ template <int NS>
 __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
 {
     __shared__ SharedRow sh;
-    for (int e = threadIdx.x; e < FastTables::kCount; e += kRowThreads) {
-        sh.h[e] = a.f.ft->H[e] / 10;   // finite entries are multiples of 10 (build_int_tables); "not available" stays huge
-        sh.g[e] = a.it->g[e];
+    for (int e = threadIdx.x; e < kRowGCount; e += kRowThreads) {
+        sh.h[e] = a.f.ft->H[kRowGBase + e] / 10;   // finite entries are multiples of 10 (build_int_tables); "not available" stays huge
+        sh.g[e] = a.it->g[kRowGBase + e];
     }
     for (int e = threadIdx.x; e < 100; e += kRowThreads)
         sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
