@@ -69,6 +69,7 @@ struct EngineOptions {
 struct msspe_ctx {
     int device = 0;
     int n_cu = 256;
+    bool lds_reads_zero = false;       // pairs_row_lds_reads_zero(): the row kernel may run
     EngineOptions opt;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -325,6 +326,9 @@ int msspe_create(int device, const char *params_path, msspe_ctx **out)
     ctx->stream = ctx->own_stream;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tb, sizeof(NNTables)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_tb, &ctx->host_tb, sizeof(NNTables), hipMemcpyHostToDevice));
+    // the row-specialised kernel drops its address clamp where LDS reads beyond the allocation return 0
+    // (thal_pairs_row.hip MSSPE_ROW_OOB): every gfx950 seen does; a device that does not runs the general kernel
+    HIP_TRY(ctx, pairs_row_lds_reads_zero(ctx->stream, &ctx->lds_reads_zero));
     return MSSPE_OK;
 }
 
@@ -710,7 +714,7 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
                 a.col1 = col0 + (int)q_end;
                 HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
             } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->opt.split_lanes, ctx->stream));
-            else if (int_stage && ce->row_ok && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
+            else if (int_stage && ce->row_ok && ctx->lds_reads_zero && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
                 HIP_TRY(ctx, launch_pairs_row(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));

@@ -125,6 +125,7 @@ hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsign
                             hipStream_t stream);
 int pairs_row_max_k();
 bool pairs_row_tables_ok(const IntTables &it);   // host: may this chemistry run the row kernel?
+hipError_t pairs_row_lds_reads_zero(hipStream_t stream, bool *ok);   // does this device read 0 beyond a block's LDS allocation?
 // List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit
 // 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,

@@ -90,18 +90,43 @@ static_assert((long long)kRowU + kNoY + kRowD < 0x7fffffffLL, "table entries are
 #ifndef MSSPE_ROW_F64MIN
 #define MSSPE_ROW_F64MIN 1
 #endif
+// MSSPE_ROW_OOB: a predecessor that is not up-left of the cell makes the 17-bit address field wrap to at least
+// kRowWrapMin; with the table placed so that those addresses lie beyond the block's LDS allocation the read
+// returns 0 (gfx950: every ds_read at or beyond the allocation, rounded up to 1,280 bytes, reads 0;
+// tools/lds_oob_probe.hip, checked again by pairs_row_lds_reads_zero() when an engine is made), and 0 is made
+// to mean "not available": every table entry carries - kRowZero and every slot value + kRowZero.  That saves
+// the unsigned min that clamped the address in every visit.  0: the clamped address of before.
+#ifndef MSSPE_ROW_OOB
+#define MSSPE_ROW_OOB 1
+#endif
+#if MSSPE_ROW_OOB
+constexpr int kRowZero = kRowU + kNoY + kRowD;   // the stored pattern of "not available" before the shift: now 0
+static_assert((long long)IntTables::kReach + kRowZero < 0x7fffffffLL, "slot values + kRowZero are int32");
+static_assert(-(long long)IntTables::kReach + kRowD - kRowZero > -0x7fffffffLL, "table entries - kRowZero are int32");
+#else
+constexpr int kRowZero = 0;
+#endif
 #ifndef MSSPE_ROW_SEG
 #define MSSPE_ROW_SEG 256
 #endif
 constexpr int kSegGroups = MSSPE_ROW_SEG;        // column groups (of 64) per work item
 // slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
 //             bits 14..0   h + kHBias
-constexpr int kEmptyRowW = ((15 * kRowA) << 17) | kHBias;  // jj = 15: right of every cell
+// an empty slot: K one beyond the largest real one (12 * 772 + 4 * 12 + 3), i.e. beyond every cell's minuend, so
+// that the difference is negative for every cell (and as large as possible after the wrap, see kRowWrapMin)
+constexpr int kEmptyRowK = (kRowK - 1) * kRowA + 4 * (kRowK - 1) + 3 + 1;
+constexpr int kEmptyRowW = (kEmptyRowK << 17) | kHBias;
+// smallest table address (bytes) of a predecessor that is not up-left of the cell: either the minuend is the
+// smallest possible (column 1, row 0: K = 3) and the word the empty one, or the cell is in column 0, whose
+// minuend wraps to 2^15 - 769 + 60 i
+constexpr int kRowWrapMin = 4 * ((1 << 15) - 769 - kEmptyRowK) < (1 << 17) - 4 * (kEmptyRowK - 3)
+                                ? 4 * ((1 << 15) - 769 - kEmptyRowK) : (1 << 17) - 4 * (kEmptyRowK - 3);
 
-// Order matters: LDS instructions take a 16-bit immediate offset, so everything that is addressed as
-// "lane + constant" or "table + index" lives in the first 64 KB and needs no address arithmetic.
+// Order matters.  LDS instructions take a 16-bit immediate offset, so what is addressed as "lane + constant" or
+// "table + index" lives in the first 64 KB and needs no address arithmetic; and (MSSPE_ROW_OOB) T sits so far
+// back that its wrapped addresses fall off the end of the allocation (static_asserts below the struct).
+constexpr int kPredLo = 24;   // rows of the predecessor bytes in front of T (the row number is a scalar: no cost)
 struct SharedRow {
-    int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
     // per-lane state that is touched once per cell (registers are the scarce resource: 104 of a lane's
     // 168 hold the table, and what does not fit goes to scratch memory, i.e. to HBM latency)
     int pick[4][kRowThreads];           // terminal pick: value, word, 0 or the tied later cells' enthalpy range (max << 16 | min, biased by
@@ -115,15 +140,28 @@ struct SharedRow {
     int h[kRowGCount];                  // enthalpy / 10 (every finite one is a multiple of 10 cal/mol)
     short TH[kRowTEntries + 4];         // enthalpy / 10 of the loop term T holds, << 1 | "the lane adds ytsh" (same index)
     double cq[100];                     // 620300 * (init_S + rS + RC) per right-end context (maxTM)
-    unsigned char pred[kRowSlots][kRowThreads];
-    unsigned short path[kPathMax][kRowThreads];
+    unsigned char pred_lo[kPredLo][kRowThreads];
     unsigned next_group;
     int item;
     // The kernel's arguments (experiment MSSPE_ROW_ARGS_LDS: read from here at the point of use they have no
     // live range across the DP; measured: scratch write-back 5.1 -> 0.9 GB per launch, but the launch takes
     // 99 ms instead of 63, the values arriving in vector registers; left off)
     IntArgs args;
+    int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
+    unsigned char pred_hi[kRowSlots - kPredLo][kRowThreads];
+    unsigned short path[kPathMax][kRowThreads];
+    __device__ __forceinline__ unsigned char &pred(int slot, int tid)   // slot: wave-uniform
+    {
+        return slot < kPredLo ? pred_lo[slot][tid] : pred_hi[slot - kPredLo][tid];
+    }
 };
+#if MSSPE_ROW_OOB
+static_assert(offsetof(SharedRow, T) <= 65532, "T is addressed with an immediate offset");
+static_assert(offsetof(SharedRow, T) + kRowWrapMin >= (sizeof(SharedRow) + 1279) / 1280 * 1280,
+              "wrapped table addresses must lie beyond the block's LDS allocation (granule: 1,280 bytes)");
+static_assert(kRowTBytes <= kRowWrapMin, "valid addresses stay inside the table");
+#endif
+static_assert(sizeof(SharedRow) <= 160 * 1024, "one block per CU");
 
 struct KParts {
     int ii, jj, n2;
@@ -216,6 +254,16 @@ __device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
 #endif
 }
 
+// the scan's address: no clamp with MSSPE_ROW_OOB (a wrapped address reads 0 = not available)
+__device__ __forceinline__ unsigned scan_index(unsigned C, unsigned W)
+{
+#if MSSPE_ROW_OOB
+    return (C - W) >> 15;
+#else
+    return row_index(C, W);
+#endif
+}
+
 // The table addresses and the (still outstanding) table values of one chunk of slots.
 struct ChunkLoad {
     unsigned idx[kC];
@@ -227,7 +275,7 @@ __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, con
 {
 #pragma unroll
     for (int e = 0; e < kC; ++e)
-        L.idx[e] = row_index(c.C, (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e));
+        L.idx[e] = scan_index(c.C, (unsigned)slot_of<NS>(Wa, Wb, Wc, PC * kC + e));
 #pragma unroll
     for (int e = 0; e < kC; ++e) L.t[e] = *(const int *)(T + L.idx[e]);
 }
@@ -257,7 +305,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD ? -kNoY : c.yTS);
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS);
                     const int cand = cur.t[e] + y + Gp;   // unavailable: kRowU + ..., never below the minimum <= kValid (all + kRowD)
                     take_min(best, cand, Wp);
                 }
@@ -266,7 +314,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD ? -kNoY : c.yTS);
+                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS);
                     const int cand = cur.t[e] + y + Gp;
                     take_min(best, cand, Wp);
                     const bool isstk = cur.idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
@@ -287,9 +335,9 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
                                                   bool decisions_only)
 {
-    v32i Ga = 0, Wa = kEmptyRowW;
-    typename TabTypes<NS>::B Gb = 0, Wb = kEmptyRowW;
-    typename TabTypes<NS>::C Gc = 0, Wc = kEmptyRowW;
+    v32i Ga = kRowZero, Wa = kEmptyRowW;   // slot values carry + kRowZero (MSSPE_ROW_OOB)
+    typename TabTypes<NS>::B Gb = kRowZero, Wb = kEmptyRowW;
+    typename TabTypes<NS>::C Gc = kRowZero, Wc = kEmptyRowW;
     int defer = 0;
     CellCtx c;
     c.rS = 0.0;
@@ -364,7 +412,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         const int pickG = sh.pick[0][threadIdx.x];
         if (stHave && !(MSSPE_KO & 4)) {
             const int h1 = word_h(stk.W) + hwc;
-            const int G1 = stk.G + gwc;
+            const int G1 = stk.G + (gwc - kRowZero);
             const double A0 = (double)(h0 + 20 + rh), A1 = (double)(h1 + 20 + rh);
             const double B0 = (double)(20000 * h0 - G0) + cq, B1 = (double)(20000 * h1 - G1) + cq;
             const double lhs = A1 * B0, rhs = A0 * B1;
@@ -405,6 +453,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         // an empty slot's value is never a candidate's winner (its word fails every geometry test), but it is
         // an operand of the sum that v_min_f64 orders: keep it a number the bounds above cover
         G0 = in ? G0 : 0;
+        const int G0s = G0 + kRowZero;   // as the slots hold it
         // ---- terminal pick (strict minimum of dG incl. the right end term, first in slot order)
         {
             const int Gt = G0 + gR;
@@ -424,27 +473,27 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         // (the cells of the last row all land in the first free slot, which the sizing keeps free: nothing
         //  reads it -- no row follows, and the walk back only matches predecessors)
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
-            Ga[slot & 31] = G0;
+            Ga[slot & 31] = G0s;
             Wa[slot & 31] = Wcell;
         } else if constexpr (NS == 64) {
-            Gb[(slot - 32) & 31] = G0;
+            Gb[(slot - 32) & 31] = G0s;
             Wb[(slot - 32) & 31] = Wcell;
         } else if constexpr (NS == 48) {
-            Gb[(slot - 32) & 15] = G0;
+            Gb[(slot - 32) & 15] = G0s;
             Wb[(slot - 32) & 15] = Wcell;
         } else {
             if (slot < 48) {
-                Gb[(slot - 32) & 15] = G0;
+                Gb[(slot - 32) & 15] = G0s;
                 Wb[(slot - 32) & 15] = Wcell;
             } else if constexpr (NS == 52) {
-                Gc[(slot - 48) & 3] = G0;
+                Gc[(slot - 48) & 3] = G0s;
                 Wc[(slot - 48) & 3] = Wcell;
             } else {
-                Gc[(slot - 48) & 7] = G0;
+                Gc[(slot - 48) & 7] = G0s;
                 Wc[(slot - 48) & 7] = Wcell;
             }
         }
-        sh.pred[slot][threadIdx.x] = (unsigned char)pred;
+        sh.pred(slot, threadIdx.x) = (unsigned char)pred;
       }
       start_im1 = row_start;
     }
@@ -483,7 +532,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
 #pragma unroll
             for (int e = kC - 1; e >= 0; --e) {
                 const int slot = pc * kC + e;
-                const int pr = sh.pred[slot][threadIdx.x];
+                const int pr = sh.pred(slot, threadIdx.x);
                 const bool hit = !done & (word_sig(W[e]) == cur);   // an empty slot matches no cell
                 if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)((unsigned)W[e] >> 17);
                 dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
@@ -729,11 +778,11 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
             if (v >= IntTables::kValid) hv = 0;
         }
         if (v >= IntTables::kValid) v = kRowU;
-        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD;
+        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD - kRowZero;   // MSSPE_ROW_OOB: "not available" is 0
         sh.TH[e] = (short)(((hv / 10) << 1) | (needs_y ? 1 : 0));
     }
     if (threadIdx.x < 4) {
-        sh.T[kRowTEntries + threadIdx.x] = kRowU + kNoY + kRowD;
+        sh.T[kRowTEntries + threadIdx.x] = kRowU + kNoY + kRowD - kRowZero;
         sh.TH[kRowTEntries + threadIdx.x] = 0;
     }
     if (threadIdx.x < 64) {
@@ -808,6 +857,52 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
 }  // namespace
 
 int pairs_row_max_k() { return kRowK; }
+
+namespace {
+// Reads the LDS addresses the row kernel's wrapped table addresses can produce, from a block with the row
+// kernel's allocation, filled with ones: every read must return 0.
+__global__ void __launch_bounds__(256) k_lds_probe(unsigned lo, unsigned hi, unsigned *nonzero)
+{
+    extern __shared__ unsigned fill[];
+    for (unsigned e = threadIdx.x; e < sizeof(SharedRow) / 4; e += blockDim.x) fill[e] = 0xffffffffu;
+    __syncthreads();
+    unsigned bad = 0;
+    for (unsigned addr = lo + 4u * threadIdx.x; addr < hi; addr += 4u * blockDim.x) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        bad |= v;
+    }
+    if (bad) atomicOr(nonzero, 1u);
+}
+}  // namespace
+
+// MSSPE_ROW_OOB rests on this (see the macro): checked once per engine, on the engine's device.
+hipError_t pairs_row_lds_reads_zero(hipStream_t stream, bool *ok)
+{
+    *ok = true;
+#if MSSPE_ROW_OOB
+    unsigned *d_flag = nullptr, h_flag = 1;
+    hipError_t e = hipMalloc((void **)&d_flag, sizeof(unsigned));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_flag, 0, sizeof(unsigned), stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lds_probe, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)sizeof(SharedRow));
+    if (e == hipSuccess) {
+        const unsigned lo = (unsigned)offsetof(SharedRow, T) + (unsigned)kRowWrapMin;
+        const unsigned hi = (unsigned)offsetof(SharedRow, T) + (1u << 17);
+        hipLaunchKernelGGL(k_lds_probe, dim3(1), dim3(256), sizeof(SharedRow), stream, lo, hi, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_flag);
+    if (e != hipSuccess) return e;
+    *ok = h_flag == 0;
+#else
+    (void)stream;
+#endif
+    return hipSuccess;
+}
 
 // The row kernel's running minimum needs every value a cell can publish to be a reachable one (kRowD above):
 // the end terms and the stacked-pair terms must all exist.  Primer3's parameter set has them all; a
