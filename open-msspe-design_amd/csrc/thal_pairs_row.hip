@@ -148,7 +148,7 @@ struct SharedRow {
     // 99 ms instead of 63, the values arriving in vector registers; left off)
     IntArgs args;
     int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
-    unsigned char pred_hi[kRowSlots - kPredLo][kRowThreads];
+    unsigned char pred_hi[kRowSlots + 1 - kPredLo][kRowThreads];   // + 1: the row the last row of a full table writes (never read)
     unsigned short path[kPathMax][kRowThreads];
     __device__ __forceinline__ unsigned char &pred(int slot, int tid)   // slot: wave-uniform
     {
@@ -470,8 +470,8 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
             }
         }
         // ---- publish the cell (idle lanes write a slot nobody reads)
-        // (the cells of the last row all land in the first free slot, which the sizing keeps free: nothing
-        //  reads it -- no row follows, and the walk back only matches predecessors)
+        // (the cells of the last row all take the first free slot number -- or 52, which is written nowhere --:
+        //  nothing reads it, no row follows and the walk back only matches predecessors)
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0s;
             Wa[slot & 31] = Wcell;
@@ -486,8 +486,10 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                 Gb[(slot - 32) & 15] = G0s;
                 Wb[(slot - 32) & 15] = Wcell;
             } else if constexpr (NS == 52) {
-                Gc[(slot - 48) & 3] = G0s;
-                Wc[(slot - 48) & 3] = Wcell;
+                if (slot < 52) {   // slot 52: the cells of the last row of a full table, written nowhere
+                    Gc[(slot - 48) & 3] = G0s;
+                    Wc[(slot - 48) & 3] = Wcell;
+                }
             } else {
                 Gc[(slot - 48) & 7] = G0s;
                 Wc[(slot - 48) & 7] = Wcell;
@@ -624,7 +626,9 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     const int last_base = (int)((q.s1 >> (2 * (k - 1))) & 3u);   // scalar
     int n_cells = n_all - c2[3 - last_base];
     const bool sym = self_complementary(pa, k) && self_complementary(pb, k);
-    constexpr int kFit = NS - 1;   // one slot stays free: the cells of the last row are written there
+    // the whole table for 52 slots (the last row's cells then take the number 52 and are written nowhere); the
+    // other shapes keep one slot free for them
+    constexpr int kFit = NS == 52 ? NS : NS - 1;
     bool spill = inside & ((n_cells > kFit) | sym);
     unsigned flag = 0u;
     bool active = inside & !spill & (n_all > 0);   // lanes that run the DP
