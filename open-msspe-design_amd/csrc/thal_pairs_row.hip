@@ -885,6 +885,15 @@ hipError_t pairs_row_lds_reads_zero(hipStream_t stream, bool *ok)
 {
     *ok = true;
 #if MSSPE_ROW_OOB
+    {   // the kernel's real LDS size (the static_asserts speak for SharedRow; a compiler could add to it)
+        hipFuncAttributes fa;
+        const hipError_t ea = hipFuncGetAttributes(&fa, (const void *)k_pairs_row<kRowSlots>);
+        if (ea != hipSuccess) return ea;
+        if (offsetof(SharedRow, T) + (size_t)kRowWrapMin < (fa.sharedSizeBytes + 1279) / 1280 * 1280) {
+            *ok = false;
+            return hipSuccess;
+        }
+    }
     unsigned *d_flag = nullptr, h_flag = 1;
     hipError_t e = hipMalloc((void **)&d_flag, sizeof(unsigned));
     if (e != hipSuccess) return e;
