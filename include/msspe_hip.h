@@ -81,6 +81,8 @@ const char *msspe_version(void);
  *   "wave_kernel"    "0" | "1"    one-wave-per-pair f64 kernel in the chain (1)
  *   "list_cap_log2"  "0" | "20".."30"   fixed hand-over list size (0: sized by the call)
  *   "split_lanes"    "0" | "2" | "4" | "8"
+ *   "split_list"     "0" | "1"    short oligos: tables too large for the integer list stage go to the split-table
+ *                                 kernel's list mode (1) or straight to the f64 kernels (0)
  *   "stage_a_graph"  "0" | "1"    hipGraph replay of stage A's greedy loop (1)
  *   "stage_a_candidates" "0" | "1"  greedy loop over the list of words near the maximum (1), or over all the
  *                                 words on every iteration (0); the winners are the same */

@@ -64,6 +64,7 @@ struct EngineOptions {
     bool wave_kernel = true;
     int list_cap_log2 = 0;    // 0: sized by the call; 20..30: fixed (forces flushes mid-screen)
     int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
+    bool split_list = true;   // short oligos: tables too large for the integer list stage go to the split kernel's list mode
 };
 
 struct msspe_ctx {
@@ -361,6 +362,9 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "split_lanes") {
         if (!is_num || !(num == 0 || num == 2 || num == 4 || num == 8)) return bad();
         ctx->opt.split_lanes = (int)num;
+    } else if (k == "split_list") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->opt.split_list = num != 0;
     } else if (k == "stage_a_graph") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->kmer.set_use_graph(num != 0);
@@ -644,6 +648,14 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
             HIP_TRY(ctx, launch_pairs_int_list(a, ce->d_it, in_list, ctx->ovf_count + in_c, ctx->d_reasons,
                                                ctx->n_cu, ctx->stream));
             advance();
+            if (ce->split_max_k >= k && ctx->opt.split_list) {
+                // (1b) tables beyond the list stage's 63 stored cells: two lanes per pair, still exact integers
+                //      (marked entries -- ties -- pass through to the f64 kernels)
+                a.overflow_list = out_list;
+                a.overflow_count = ctx->ovf_count + out_c;
+                HIP_TRY(ctx, launch_pairs_split_list(a, ce->d_st, in_list, ctx->ovf_count + in_c, ctx->n_cu, ctx->stream));
+                advance();
+            }
             a.overflow_list = out_list;
             a.overflow_count = ctx->ovf_count + out_c;
             HIP_TRY(ctx, launch_pairs_main_list(a, in_list, ctx->ovf_count + in_c, ctx->stream));

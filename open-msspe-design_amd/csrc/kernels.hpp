@@ -134,6 +134,8 @@ hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, c
 // a pair's table split over 2, 4 or 8 lanes; same contract as launch_pairs_int (a.ft is not used).
 hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, unsigned long long *reasons,
                               int lanes, hipStream_t stream);
+hipError_t launch_pairs_split_list(const PairKernelArgs &a, const SplitTables *st, const uint2 *in_list,
+                                   const uint32_t *in_count, int n_cu, hipStream_t stream);
 int pairs_split_lanes(int k);
 // f64 DP with one wave per pair (thal_pairs_wave.hip), oligos up to st->f64_max_k bases.  in_list:
 // explicit pairs (count *in_count, at most a.overflow_cap); nullptr: the block rows [a.row0, a.row1) x

@@ -452,7 +452,10 @@ struct SplitArgs {
     uint32_t ovf_cap;
     unsigned long long *reasons;   // optional statistics, layout of thal_pairs_int.hip's matrix mode
     unsigned *work_counter;        // next work item, zero at launch
+    const uint2 *in_list;          // list mode: explicit pairs (row | kNeedsF64 mark, col)
+    const uint32_t *in_count;
 };
+constexpr unsigned kMarkF64 = 0x80000000u;   // int_core.hpp kNeedsF64: an exact tie was met, only the f64 kernels answer
 
 __device__ __forceinline__ void load_tables_s(SharedS &sh, const SplitArgs &a)
 {
@@ -470,34 +473,54 @@ __device__ __forceinline__ void load_tables_s(SharedS &sh, const SplitArgs &a)
 }
 
 // Matrix mode: wave = one row x 64 / Q consecutive entries of the composition-sorted column list.
-template <int Q>
+// List mode (LIST): wave = 64 / Q consecutive entries of a hand-over list.  Entries that carry the tie mark are
+// passed on untouched (this kernel would meet the same tie); the others left the integer stages for their size
+// only, and two lanes per pair hold tables twice as large.
+template <int Q, bool LIST>
 __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
 {
     __shared__ SharedS sh;
     load_tables_s(sh, a);
     constexpr int kPairsPerWave = 64 / Q;
     const int lane = threadIdx.x & 63;
-    const int ncolg = (a.col1 - a.col0 + kPairsPerWave - 1) / kPairsPerWave;
-    // work items (one row x 64 / Q consecutive sorted columns) are handed to the waves from a counter
-    // (fixed strides would tie every block to a few composition classes of very different cost)
-    const unsigned n_items = (unsigned)ncolg * (unsigned)(a.row1 - a.row0);
+    const int ncolg = LIST ? 1 : (a.col1 - a.col0 + kPairsPerWave - 1) / kPairsPerWave;
+    const unsigned n_list = LIST ? min(*a.in_count, a.ovf_cap) : 0u;
+    // work items (one row x 64 / Q consecutive sorted columns, or 64 / Q list entries) are handed to the waves
+    // from a counter (fixed strides would tie every block to a few composition classes of very different cost)
+    const unsigned n_items = LIST ? (n_list + kPairsPerWave - 1) / kPairsPerWave
+                                  : (unsigned)ncolg * (unsigned)(a.row1 - a.row0);
     for (;;) {
         unsigned item = 0;
         if (lane == 0) item = atomicAdd(a.work_counter, 1u);
         item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= n_items) break;   // wave-uniform
-        const int row = a.row0 + (int)(item / (unsigned)ncolg), cg = (int)(item % (unsigned)ncolg);
-        const int cq = a.col0 + cg * kPairsPerWave + lane / Q;
-        const bool inside = cq < a.col1;
+        int row, col;
+        bool inside, marked = false;
+        uint64_t pa, pb;
+        if (LIST) {
+            const unsigned e = item * kPairsPerWave + (unsigned)(lane / Q);
+            inside = e < n_list;
+            const uint2 pr = a.in_list[inside ? e : 0];
+            marked = (pr.x & kMarkF64) != 0u;
+            row = (int)(pr.x & ~kMarkF64);
+            col = (int)pr.y;
+            pa = a.pool[row];
+            pb = a.pool[col];
+        } else {
+            row = a.row0 + (int)(item / (unsigned)ncolg);
+            const int cg = (int)(item % (unsigned)ncolg);
+            const int cq = a.col0 + cg * kPairsPerWave + lane / Q;
+            inside = cq < a.col1;
+            pa = a.pool[row];
+            pb = a.cols_sorted[inside ? cq : a.col0];
+            col = (int)a.perm[inside ? cq : a.col0];
+        }
         const bool head = (lane & (Q - 1)) == 0;   // the lane that reports for its group
-        const uint64_t pa = a.pool[row];
-        const uint64_t pb = a.cols_sorted[inside ? cq : a.col0];
-        const int col = (int)a.perm[inside ? cq : a.col0];
         SeqW q;
         unsigned long long rowmask;
         int n_cells = setup_pair_w(pa, pb, a.k, q, rowmask);
         const bool sym = self_complementary(pa, a.k) && self_complementary(pb, a.k);
-        bool spill = inside & ((n_cells > kLaneSlots * Q) | sym);
+        bool spill = inside & ((n_cells > kLaneSlots * Q) | sym | marked);
         if (!inside | spill) n_cells = 0;
         const int nmax = wave_max_s(n_cells);
         SplitResult r;
@@ -511,7 +534,8 @@ __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
         spill |= deferred;
         if (spill & head) {
             const uint32_t at = atomicAdd(a.ovf_count, 1u);
-            if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
+            if (at < a.ovf_cap)
+                a.ovf_list[at] = make_uint2((unsigned)row | ((LIST && (marked | deferred)) ? kMarkF64 : 0u), (unsigned)col);
         }
         if (a.reasons) {
             const unsigned long long dm = __ballot(deferred & head);
@@ -533,8 +557,12 @@ __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
                      1ull << (ocol & 63));
         if (hit) sink_edge(a.sinks, row, col, r.dG);
         if (a.sinks.row_conflicts) {
-            const unsigned long long bits = __ballot(hit);
-            if (lane == 0 && bits) atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+            if (LIST) {
+                if (hit) atomicAdd(&a.sinks.row_conflicts[row], 1u);   // the lanes' rows differ
+            } else {
+                const unsigned long long bits = __ballot(hit);
+                if (lane == 0 && bits) atomicAdd(&a.sinks.row_conflicts[row], (unsigned)__popcll(bits));
+            }
         }
         if (live) {
             if (a.sinks.dg) a.sinks.dg[orow * (size_t)a.sinks.ncols + ocol] = r.dG;
@@ -572,9 +600,40 @@ hipError_t launch_pairs_split(const PairKernelArgs &a, const SplitTables *st, un
     const long tiles = (long)((a.col1 - a.col0 + 64 / Q - 1) / (64 / Q)) * (long)((a.row1 - a.row0 + 7) / 8);
     if (tiles <= 0) return hipSuccess;
     const int grid = (int)(tiles < 256L ? tiles : 256L);   // one persistent block per CU (about 150 KB of LDS)
-    if (Q == 2) hipLaunchKernelGGL(k_pairs_split<2>, dim3(grid), dim3(kThreadsS), 0, stream, x);
-    else if (Q == 4) hipLaunchKernelGGL(k_pairs_split<4>, dim3(grid), dim3(kThreadsS), 0, stream, x);
-    else hipLaunchKernelGGL(k_pairs_split<8>, dim3(grid), dim3(kThreadsS), 0, stream, x);
+    x.in_list = nullptr;
+    x.in_count = nullptr;
+    if (Q == 2) hipLaunchKernelGGL((k_pairs_split<2, false>), dim3(grid), dim3(kThreadsS), 0, stream, x);
+    else if (Q == 4) hipLaunchKernelGGL((k_pairs_split<4, false>), dim3(grid), dim3(kThreadsS), 0, stream, x);
+    else hipLaunchKernelGGL((k_pairs_split<8, false>), dim3(grid), dim3(kThreadsS), 0, stream, x);
+    return hipGetLastError();
+}
+
+// List mode, two lanes per pair: the unmarked entries of a hand-over list (tables too large for the integer
+// list stage) in exact integers; marked entries and what this kernel cannot answer go to the output list.
+hipError_t launch_pairs_split_list(const PairKernelArgs &a, const SplitTables *st, const uint2 *in_list,
+                                   const uint32_t *in_count, int n_cu, hipStream_t stream)
+{
+    SplitArgs x;
+    x.st = st;
+    x.c = a.c;
+    x.pool = a.pool;
+    x.cols_sorted = nullptr;
+    x.perm = nullptr;
+    x.k = a.k;
+    x.row0 = a.row0;
+    x.row1 = a.row1;
+    x.col0 = a.col0;
+    x.col1 = a.col1;
+    x.sinks = a.sinks;
+    x.ovf_list = a.overflow_list;
+    x.ovf_count = a.overflow_count;
+    x.ovf_cap = a.overflow_cap;
+    x.reasons = nullptr;
+    x.work_counter = a.work_counter;
+    x.in_list = in_list;
+    x.in_count = in_count;
+    if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_pairs_split<2, true>), dim3(n_cu > 0 ? n_cu : 256), dim3(kThreadsS), 0, stream, x);
     return hipGetLastError();
 }
 

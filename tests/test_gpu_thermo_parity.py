@@ -237,6 +237,27 @@ def test_pairs_without_a_complementary_cell(eng, m, oracle, oracle_tables, k, pa
     assert cnt > 0
 
 
+@pytest.mark.parametrize("split_list", [1, 0])
+def test_very_large_tables_of_short_oligos(eng, m, oracle, oracle_tables, split_list):
+    """A/T-only and G/C-only 13-mers against each other: 60 ... 169 complementary cells per pair, far beyond the
+    integer stages' tables.  With split_list = 1 they go through the split-table kernel's list mode (two lanes
+    per pair, up to 128 cells; all-A against all-T is left to the one-wave-per-pair kernel), with 0 straight
+    to the f64 kernels: same planes, bit for bit, as the oracle's."""
+    rng = np.random.default_rng(44)
+    at = np.frombuffer(b"AT", dtype=np.uint8)[rng.integers(0, 2, (110, 13))]
+    gc = np.frombuffer(b"GC", dtype=np.uint8)[rng.integers(0, 2, (90, 13))]
+    homo = np.frombuffer(b"AAAAAAAAAAAAATTTTTTTTTTTTTGGGGGGGGGGGGGCCCCCCCCCCCCC", dtype=np.uint8).reshape(4, 13)
+    pool = m.synth.pool_strings(np.concatenate([at, gc, homo, m.synth.random_pool(52, 13, seed=9)]))
+    eng.set_option("split_list", split_list)
+    try:
+        out, cnt = check_pool(eng, m, oracle, oracle_tables, pool, threshold=-6000.0)
+        fast = eng.cross_dimer(pool, m.Chem.ntthal(), -6000.0, want_dg=False, want_tm=False)
+    finally:
+        eng.set_option("split_list", 1)
+    np.testing.assert_array_equal(fast["bitmap"], out["bitmap"])
+    assert cnt > 1000
+
+
 def test_hand_over_lists_shrink_when_the_card_is_full(m):
     """A 32,768-primer screen (2^30 pairs) asks for two hand-over lists of 8 GB; with only 10 GB left on the
     card the engine takes smaller lists (more flushes) and the screen comes out the same."""
