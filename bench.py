@@ -60,6 +60,13 @@ def parse_args():
     ap.add_argument("--stage-a", dest="stage_a", action="store_true", default=None,
                     help="also time stage A on 10,000 x 30 kb synthetic genomes (default: on at N = 1)")
     ap.add_argument("--no-stage-a", dest="stage_a", action="store_false")
+    ap.add_argument("--stage-b", dest="stage_b", action="store_true", default=None,
+                    help="also time stage B (Tm / GC / SELF_ANY / SELF_END / HAIRPIN) on 2,000 and 1,048,576 oligos "
+                         "(default: on at N = 1)")
+    ap.add_argument("--no-stage-b", dest="stage_b", action="store_false")
+    ap.add_argument("--max-seconds", type=float, default=600.0,
+                    help="--config pool1m only: the timed region's budget; the step count is cut to fit it "
+                         "(one step is 1.1e12 checks: about 9 minutes on one GPU, about 70 s on eight)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -160,6 +167,63 @@ def stage_a_line(eng, device):
     return out
 
 
+def stage_b_line(eng, device, cpu_seconds: float):
+    """Stage B (od-msspe/src/primer.rs:143-166: what the reference gets from primer3_core per candidate) with the
+    oligos resident in HBM: Tm + GC %, SELF_ANY, SELF_END (thal ANY / END1 of the oligo with itself) and HAIRPIN,
+    at 2,000 oligos (what the reference's loop produces, main.rs:344) and at 1,048,576 (configs[3]'s pool).
+    Every part is timed on its own with HIP events on the engine's stream; the CPU restatement runs beside it on a
+    bounded sample and its five numbers per oligo are compared bit for bit."""
+    chem = msspe_amd.Chem.primer3()
+    out = {"chemistry": "primer3_core defaults (mv 50, dv 1.5, dNTP 0.6, 50 nM, 37 C)", "sizes": {}}
+    for n in (2000, 1 << 20):
+        pool_ascii = msspe_amd.synth.random_pool(n, K, seed=2000 + n)
+        d_pool = torch.from_numpy(msspe_amd.pack_oligos(pool_ascii).view(np.int64)).to(device)
+        d_out = torch.zeros((5, n), dtype=torch.float64, device=device)
+        ptr = [d_out[q].data_ptr() for q in range(5)]
+        parts = {"tm_gc": (ptr[0], ptr[1], 0, 0, 0), "self_any": (0, 0, ptr[2], 0, 0),
+                 "self_end": (0, 0, 0, ptr[3], 0), "hairpin": (0, 0, 0, 0, ptr[4]), "all": tuple(ptr)}
+        times = {}
+        for name, a in parts.items():
+            call = lambda: eng.oligo_stats_dev(d_pool.data_ptr(), n, K, chem, *a)
+            call()
+            torch.cuda.synchronize()
+            reps = 20 if n <= 4096 else 3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            times[name] = e0.elapsed_time(e1) / reps
+        entry = {"ms": times, "oligos_per_s": n / (times["all"] * 1e-3),
+                 "dp_checks_per_s": {q: n / (times[q] * 1e-3) for q in ("self_any", "self_end", "hairpin")},
+                 # the two dimer DPs of an oligo with itself are ordinary thal checks: priced like the headline
+                 # kernel, reference f64 operations per check against the FP64 vector peak
+                 "roofline_frac_self_dimers": 2 * n * F64_OPS_PER_CHECK /
+                                              ((times["self_any"] + times["self_end"]) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        out["sizes"][str(n)] = entry
+        if n > 2000:
+            # the CPU restatement beside it, on a bounded sample of the same oligos (OpenMP over oligos)
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import pyoracle
+            tables = pyoracle.Tables()
+            m_cpu = 1 << 18
+            words = msspe_amd.synth.pool_strings(pool_ascii[:m_cpu])
+            cores = min(os.cpu_count() or 1, 16)
+            t0 = time.perf_counter()
+            ref = pyoracle.check_primers(tables, words)
+            dt = time.perf_counter() - t0
+            got = d_out[:, :m_cpu].cpu().numpy()
+            equal = all(np.array_equal(got[q], ref[key]) for q, key in
+                        enumerate(("tm", "gc", "self_any_th", "self_end_th", "hairpin_th")))
+            out["cpu_baseline"] = {"value": m_cpu / dt, "unit": "oligos/s", "cores": cores, "kind": "port",
+                                   "sample": f"the first {m_cpu} of the {n} oligos, {dt:.2f} s, OpenMP over oligos; CPU "
+                                             f"restatement of primer3_core's check_primers arithmetic",
+                                   "five_statistics_equal_gpu": bool(equal)}
+        del d_pool, d_out
+    return out
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with no launcher: start N ranks as a CHILD process (never exec from a
     process that may have touched the GPU; this one has not) and hand its exit status on."""
@@ -229,15 +293,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    steps, warmup = args.steps, args.warmup
+    if strong:
+        # One step of the 1,048,576 pool is 1.1e12 checks (minutes): the requested counts are cut to what fits
+        # --max-seconds, from one fenced step that also serves as the first warm-up step.  Every rank takes the
+        # slowest rank's estimate, so all of them run the same number of steps.
+        fence()
+        t0 = time.perf_counter()
         step()
+        fence()
+        est = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        all_reduce(est, dist.ReduceOp.MAX)
+        per_step = max(float(est.item()), 1e-3)
+        steps = max(1, min(args.steps, int(args.max_seconds / per_step)))
+        warmup = max(0, min(args.warmup - 1, int(0.25 * args.max_seconds / per_step)))
+        warmup_done = 1
+    else:
+        warmup_done = 0
+    for _ in range(warmup):
+        step()
+    warmup_done += warmup
     fence()
     eng.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    steps_requested, warmup_requested = args.steps, args.warmup
+    args.steps, args.warmup = steps, warmup_done     # what ran: every figure below is per step that ran
     launches, kernel_ms = eng.profile_read()
     eng.profile_enable(False)
     overflow = eng.last_overflow_pairs()
@@ -327,8 +411,11 @@ def main():
             cpu = cpu_baseline(pool_ascii, args.cpu_seconds,
                                d_bitmap[:min(4096, shard)].cpu().numpy().view(np.uint64) if want_bitmap else None)
         stage_a = None
-        if args.stage_a if args.stage_a is not None else (world == 1 and not args.pool):
+        if args.stage_a if args.stage_a is not None else (world == 1 and not args.pool and not strong):
             stage_a = stage_a_line(eng, dev)
+        stage_b = None
+        if args.stage_b if args.stage_b is not None else (world == 1 and not args.pool and not strong):
+            stage_b = stage_b_line(eng, dev, args.cpu_seconds)
         out = {
             "metric": "primer-pair thermo checks/sec (all-pairs cross-dimer)",
             "value": value, "unit": "checks/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -347,7 +434,12 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_a": stage_a,
+            "stage_b": stage_b,
         }
+        if strong:
+            out["steps_requested"], out["warmup_requested"] = steps_requested, warmup_requested
+            out["note"] = (f"pool1m: step counts cut to the --max-seconds {args.max_seconds:.0f} budget "
+                           f"({per_step:.1f} s per step); steps / warmup are what ran")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()   # rank 0 is still timing the CPU baseline: the ranks leave together

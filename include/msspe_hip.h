@@ -83,10 +83,20 @@ const char *msspe_version(void);
  *   "split_lanes"    "0" | "2" | "4" | "8"
  *   "split_list"     "0" | "1"    short oligos: tables too large for the integer list stage go to the split-table
  *                                 kernel's list mode (1) or straight to the f64 kernels (0)
+ *   "row_oob"        "0" | "1"    the row-specialised first stage, which reads LDS beyond its allocation and takes the
+ *                                 0 gfx950 returns there for "not available" (1; it also needs the per-engine probe to
+ *                                 pass), or the general integer kernel, which never leaves its allocation (0: for
+ *                                 debugger / trap-handler sessions that raise MEM_VIOL on such reads)
  *   "stage_a_graph"  "0" | "1"    hipGraph replay of stage A's greedy loop (1)
  *   "stage_a_candidates" "0" | "1"  greedy loop over the list of words near the maximum (1), or over all the
  *                                 words on every iteration (0); the winners are the same */
 int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value);
+/* Facts about the context's device and what it will run (engine-only diagnostics, no reference counterpart):
+ *   "device"          HIP ordinal           "n_cu"  compute units
+ *   "lds_reads_zero"  1: the per-engine probe found that LDS reads beyond a block's allocation return 0 (every
+ *                     gfx950 seen), i.e. the row-specialised first stage may run; 0: the general kernel runs
+ *   "row_kernel"      1: 13-mer pools go to the row-specialised first stage with the current options */
+int msspe_get_info(msspe_ctx *ctx, const char *key, long long *value_out);
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
 int msspe_reset_stream(msspe_ctx *ctx);
 int msspe_synchronize(msspe_ctx *ctx);

@@ -64,6 +64,7 @@ struct EngineOptions {
     bool wave_kernel = true;
     int list_cap_log2 = 0;    // 0: sized by the call; 20..30: fixed (forces flushes mid-screen)
     int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
+    bool row_oob = true;      // the row-specialised first stage (it reads LDS beyond its allocation: thal_pairs_row.hip) may run
     bool split_list = true;   // short oligos: tables too large for the integer list stage go to the split kernel's list mode
 };
 
@@ -87,8 +88,9 @@ struct msspe_ctx {
     uint64_t *d_ovf_total = nullptr;   // [0] pairs handed on so far, [1] != 0: a list counter went past its capacity
     unsigned long long *d_reasons = nullptr;   // [8] statistics of the integer stage
     uint64_t *d_sorted = nullptr;      // column primers grouped by composition
-    uint32_t *d_perm = nullptr, *d_bins = nullptr;
-    size_t sort_cap = 0;
+    uint32_t *d_perm = nullptr;
+    void *d_sort_scratch = nullptr;    // keys, values and rocPRIM temporary storage of the composition sort
+    size_t sort_cap = 0, sort_scratch_bytes = 0;
     std::string err;
     KmerStage kmer;
     // optional profiling of the dominant kernel (k_pairs_fast) with HIP events on ctx->stream
@@ -245,16 +247,18 @@ int ensure_overflow(msspe_ctx *ctx, long total_pairs)
 
 int ensure_sort(msspe_ctx *ctx, size_t ncols)
 {
-    if (!ctx->d_bins)
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_bins, sizeof(uint32_t) * (size_t)pool_sort_bins()));
     if (ctx->sort_cap >= ncols) return MSSPE_OK;
     if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
     if (ctx->d_perm) (void)hipFree(ctx->d_perm);
+    if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
     ctx->d_sorted = nullptr;
     ctx->d_perm = nullptr;
+    ctx->d_sort_scratch = nullptr;
     ctx->sort_cap = 0;
+    ctx->sort_scratch_bytes = pool_sort_scratch_bytes(ncols);
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_sorted, sizeof(uint64_t) * ncols));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_perm, sizeof(uint32_t) * ncols));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_sort_scratch, ctx->sort_scratch_bytes));
     ctx->sort_cap = ncols;
     return MSSPE_OK;
 }
@@ -328,8 +332,9 @@ int msspe_create(int device, const char *params_path, msspe_ctx **out)
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_tb, sizeof(NNTables)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_tb, &ctx->host_tb, sizeof(NNTables), hipMemcpyHostToDevice));
     // the row-specialised kernel drops its address clamp where LDS reads beyond the allocation return 0
-    // (thal_pairs_row.hip MSSPE_ROW_OOB): every gfx950 seen does; a device that does not runs the general kernel
-    HIP_TRY(ctx, pairs_row_lds_reads_zero(ctx->stream, &ctx->lds_reads_zero));
+    // (thal_pairs_row.hip kRowZero): every gfx950 seen does; a device that does not, and a context with option
+    // row_oob = 0 (debugger sessions that trap on out-of-range LDS accesses), runs the general integer kernel
+    HIP_TRY(ctx, pairs_row_lds_reads_zero(ctx->stream, ctx->n_cu, &ctx->lds_reads_zero));
     return MSSPE_OK;
 }
 
@@ -365,6 +370,9 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "split_list") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->opt.split_list = num != 0;
+    } else if (k == "row_oob") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->opt.row_oob = num != 0;
     } else if (k == "stage_a_graph") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->kmer.set_use_graph(num != 0);
@@ -374,6 +382,20 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else {
         return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: unknown option '" + k + "'");
     }
+    return MSSPE_OK;
+}
+
+int msspe_get_info(msspe_ctx *ctx, const char *key, long long *value_out)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!key || !value_out) return fail(ctx, MSSPE_ERR_ARG, "msspe_get_info: null key or output");
+    const std::string k(key);
+    if (k == "device") *value_out = ctx->device;
+    else if (k == "n_cu") *value_out = ctx->n_cu;
+    else if (k == "lds_reads_zero") *value_out = ctx->lds_reads_zero ? 1 : 0;
+    else if (k == "row_kernel")
+        *value_out = ctx->lds_reads_zero && ctx->opt.row_oob && ctx->opt.pair_kernel == 0 && !ctx->opt.force_generic ? 1 : 0;
+    else return fail(ctx, MSSPE_ERR_ARG, "msspe_get_info: unknown key '" + k + "'");
     return MSSPE_OK;
 }
 
@@ -400,7 +422,7 @@ void msspe_destroy(msspe_ctx *ctx)
         if (ctx->d_reasons) (void)hipFree(ctx->d_reasons);
         if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
         if (ctx->d_perm) (void)hipFree(ctx->d_perm);
-        if (ctx->d_bins) (void)hipFree(ctx->d_bins);
+        if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
         if (ctx->d_tb) (void)hipFree(ctx->d_tb);
         for (auto &ev : ctx->prof_events) {
             (void)hipEventDestroy(ev.first);
@@ -563,7 +585,11 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     g.wsS = ctx->wsS;
     g.wsH = ctx->wsH;
     g.ws_lanes = kGenericLanes;
-    long rows_per_chunk = kChunkPairs / ncols;
+    // A launch covers at most kChunkPairs pairs, and never more than one hand-over list holds (a fixed
+    // list_cap_log2 below 27, or lists shrunk because the card is short of memory): even a launch that handed
+    // every pair on cannot overrun its list.
+    const long chunk_pairs = std::min(kChunkPairs, kListCap);
+    long rows_per_chunk = chunk_pairs / ncols;
     // whole row groups of the first-stage kernels (12 or 8 waves per block): no idle waves in the
     // last tile row of a launch
     if (rows_per_chunk > 24) rows_per_chunk -= rows_per_chunk % 24;
@@ -587,8 +613,9 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     const bool int_stage = !split && ce->int_ok && !(ctx->opt.pair_kernel == 1);
     if (!wave_matrix) {
         if ((rc = ensure_sort(ctx, (size_t)ncols))) return rc;
-        HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_bins, ctx->d_sorted,
-                                                 ctx->d_perm, ctx->stream));
+        HIP_TRY(ctx, sort_columns_by_composition(d_pool, col0, ncols, k, ctx->d_sort_scratch,
+                                                 ctx->sort_scratch_bytes, ctx->d_sorted, ctx->d_perm,
+                                                 ctx->stream));
     }
     // Overflow pairs are collected over several launches and finished together: the list kernels
     // have a fixed latency floor, and list_cap entries cannot be overrun by list_cap / kChunkPairs
@@ -687,8 +714,8 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     long pending = 0;   // worst-case entries the list may hold
     for (int r = row0; r < row1; r += (int)rows_per_chunk) {
         const int r_end = (int)std::min<long>(row1, (long)r + rows_per_chunk);
-        for (long q0 = 0; q0 < ncols; q0 += kChunkPairs) {   // sorted-column index range
-            const long q_end = std::min<long>(ncols, q0 + kChunkPairs);
+        for (long q0 = 0; q0 < ncols; q0 += chunk_pairs) {   // sorted-column index range (one chunk unless a row is longer than a launch)
+            const long q_end = std::min<long>(ncols, q0 + chunk_pairs);
             const long launch_pairs = (long)(r_end - r) * (q_end - q0);
             if (pending + launch_pairs > kListCap) {
                 if ((rc = flush())) return rc;
@@ -726,7 +753,7 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
                 a.col1 = col0 + (int)q_end;
                 HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
             } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->opt.split_lanes, ctx->stream));
-            else if (int_stage && ce->row_ok && ctx->lds_reads_zero && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
+            else if (int_stage && ce->row_ok && ctx->lds_reads_zero && ctx->opt.row_oob && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
                 HIP_TRY(ctx, launch_pairs_row(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));

@@ -37,11 +37,7 @@ __device__ __forceinline__ bool tied_pick_cannot_conflict(const ThalConsts &K, d
     const double dH = psi * 10.0 * (psi >= 0.0 ? (double)min(dh_min, 0) : (double)max(dh_max, 0));   // <= 0
     const double per = K.temp_k * K.salt;
     const double dN = per < 0.0 ? per * (double)N : -per * (double)(kPathMax - 1 - N);              // <= 0
-#ifdef MSSPE_PICK_NAIVE   // development aid: the bound without its two terms (wrong; shows what the tests catch)
-    return G > K.g_cut + kPickMargin;
-#else
     return (G + dH) + dN > K.g_cut + kPickMargin;
-#endif
 }
 constexpr int kDragCost = 32;      // slots^2 a lane must save its wave to be sent to the list stage (tuned on 65,536 primers)
 constexpr int kEmptyW = 0xff;      // coordinates (15, 15): fails every geometry test

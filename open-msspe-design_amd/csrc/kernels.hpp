@@ -125,7 +125,7 @@ hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsign
                             hipStream_t stream);
 int pairs_row_max_k();
 bool pairs_row_tables_ok(const IntTables &it);   // host: may this chemistry run the row kernel?
-hipError_t pairs_row_lds_reads_zero(hipStream_t stream, bool *ok);   // does this device read 0 beyond a block's LDS allocation?
+hipError_t pairs_row_lds_reads_zero(hipStream_t stream, int n_cu, bool *ok);   // does this device read 0 beyond a block's LDS allocation?
 // List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit
 // 31 of .x) with a 64-slot table in lanes sorted by table size; everything else passes through.
 hipError_t launch_pairs_int_list(const PairKernelArgs &a, const IntTables *it, const uint2 *in_list,
@@ -150,9 +150,10 @@ hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const ui
                             uint32_t list_cap, uint32_t *work_counter, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
-int pool_sort_bins();
-hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k,
-                                       uint32_t *bins, uint64_t *sorted, uint32_t *perm,
+// Stable grouping of the column primers by base composition (pool_sort.hip).
+size_t pool_sort_scratch_bytes(size_t ncols);
+hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k, void *scratch,
+                                       size_t scratch_bytes, uint64_t *sorted, uint32_t *perm,
                                        hipStream_t stream);
 int pairs_fast_main_slots();
 int pairs_fast_wide_slots();

@@ -28,11 +28,6 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
 
-// development aid: knock-outs for timing experiments (wrong results), see tools/variant_build_file.sh
-#ifndef MSSPE_SA_KO
-#define MSSPE_SA_KO 0
-#endif
-
 namespace msspe {
 
 namespace {
@@ -661,8 +656,6 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
     const unsigned ns = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
         if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
-    } else if (MSSPE_SA_KO & 4) {   // no scoring: the first word of each block's share wins
-        if (tid == 0 && (nl || ns)) best = winner_key(1.0f, nl ? own_long[0] : own_short[0]);
     } else {
         for (unsigned j = 0; j < nl; ++j) {
             const uint32_t kid = own_long[j];
@@ -755,7 +748,7 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
             if (rep) old_stamp = atomicExch(&stamp[part], it1);
         }
         __syncthreads();
-        if (any_live && !(MSSPE_SA_KO & 2)) {
+        if (any_live) {
             for (int q0 = 0; q0 < per; q0 += 64) {
                 int32_t v[16];
 #pragma unroll
@@ -779,10 +772,10 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                         const int l = __ffsll((long long)mk) - 1;
                         const int32_t kl = __builtin_amdgcn_readlane(k2, l);
                         const unsigned long long same = __ballot(k2 == kl);
-                        if (!(MSSPE_SA_KO & 1) && lane == l) atomicSub(&count[kl], (int)__popcll(same));
+                        if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
                         mk &= ~same;
                     }
-                    if (!(MSSPE_SA_KO & 1) && ((mk >> lane) & 1ull)) atomicSub(&count[k2], 1);
+                    if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
                 }
                 __syncthreads();
             }

@@ -10,6 +10,8 @@
 
 #include <cstdint>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 namespace msspe {
 
 namespace {
@@ -28,68 +30,56 @@ __device__ __forceinline__ int composition_bin(uint64_t w, int k)
     return (cnt[0] * 33 + c1) * 33 + c2;
 }
 
-__global__ void k_hist(const uint64_t *pool, int col0, int ncols, int k, uint32_t *bins)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < ncols) atomicAdd(&bins[composition_bin(pool[col0 + q], k)], 1u);
-}
-
-__global__ void k_scan(uint32_t *bins)   // exclusive scan of kBins counters, one block
-{
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    constexpr int per = (kBins + 1023) / 1024;
-    uint32_t local[per];
-    uint32_t sum = 0;
-    for (int e = 0; e < per; ++e) {
-        const int idx = t * per + e;
-        local[e] = idx < kBins ? bins[idx] : 0u;
-        sum += local[e];
-    }
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = t ? part[t - 1] : 0u;
-    for (int e = 0; e < per; ++e) {
-        const int idx = t * per + e;
-        if (idx < kBins) bins[idx] = run;
-        run += local[e];
-    }
-}
-
-__global__ void k_scatter(const uint64_t *pool, int col0, int ncols, int k, uint32_t *cursor,
-                          uint64_t *sorted, uint32_t *perm)
+// key of column q = its composition bin (16 bits); value = its pool index
+__global__ void k_bin_keys(const uint64_t *pool, int col0, int ncols, int k, uint32_t *keys, uint32_t *vals)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ncols) return;
-    const uint64_t w = pool[col0 + q];
-    const uint32_t at = atomicAdd(&cursor[composition_bin(w, k)], 1u);
-    sorted[at] = w;
-    perm[at] = (uint32_t)(col0 + q);
+    keys[q] = (uint32_t)composition_bin(pool[col0 + q], k);
+    vals[q] = (uint32_t)(col0 + q);
 }
+
+__global__ void k_gather_sorted(const uint64_t *pool, int ncols, const uint32_t *perm, uint64_t *sorted)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < ncols) sorted[q] = pool[perm[q]];
+}
+
+static_assert(kBins <= (1 << 16), "the composition bin is sorted as a 16-bit key");
 
 }  // namespace
 
-int pool_sort_bins() { return kBins; }
+// Scratch the sort needs for ncols columns: two key arrays, one value array and rocPRIM's temporary storage.
+size_t pool_sort_scratch_bytes(size_t ncols)
+{
+    size_t tmp = 0;
+    uint32_t *nk = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, nk, nk, nk, nk, ncols, 0u, 16u, (hipStream_t) nullptr);
+    const size_t arr = (sizeof(uint32_t) * ncols + 255) & ~(size_t)255;
+    return 3 * arr + tmp;
+}
 
-// sorted[0..ncols) = the primers pool[col0..col0+ncols) grouped by composition;
-// perm[q] = original pool index of sorted[q].  bins: scratch of pool_sort_bins() uint32.
-hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k,
-                                       uint32_t *bins, uint64_t *sorted, uint32_t *perm,
+// sorted[0..ncols) = the primers pool[col0..col0+ncols) grouped by composition, columns of one composition in
+// ascending pool order (a STABLE sort: the lane a pair runs in, hence which pairs share a wave, which are
+// handed on for their wave's sake and every stage counter, is the same in every run);
+// perm[q] = original pool index of sorted[q].  scratch: pool_sort_scratch_bytes(ncols) bytes.
+hipError_t sort_columns_by_composition(const uint64_t *pool, int col0, int ncols, int k, void *scratch,
+                                       size_t scratch_bytes, uint64_t *sorted, uint32_t *perm,
                                        hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(bins, 0, sizeof(uint32_t) * kBins, stream);
-    if (e != hipSuccess) return e;
+    const size_t arr = (sizeof(uint32_t) * (size_t)ncols + 255) & ~(size_t)255;
+    if (scratch_bytes < 3 * arr) return hipErrorInvalidValue;
+    uint32_t *keys_in = (uint32_t *)scratch;
+    uint32_t *keys_out = (uint32_t *)((char *)scratch + arr);
+    uint32_t *vals_in = (uint32_t *)((char *)scratch + 2 * arr);
+    void *tmp = (char *)scratch + 3 * arr;
+    size_t tmp_bytes = scratch_bytes - 3 * arr;
     const int grid = (ncols + 255) / 256;
-    hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, stream, pool, col0, ncols, k, bins);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, bins);
-    hipLaunchKernelGGL(k_scatter, dim3(grid), dim3(256), 0, stream, pool, col0, ncols, k, bins, sorted,
-                       perm);
+    hipLaunchKernelGGL(k_bin_keys, dim3(grid), dim3(256), 0, stream, pool, col0, ncols, k, keys_in, vals_in);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, perm, (size_t)ncols, 0u,
+                                             16u, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gather_sorted, dim3(grid), dim3(256), 0, stream, pool, ncols, perm, sorted);
     return hipGetLastError();
 }
 

@@ -519,8 +519,10 @@ __device__ __forceinline__ void wave_pairs(SH &sh, const IntArgs &a, int row, in
     int nmax = wave_max_u8(n_cells);
     // Lock-step lanes pay for the largest table of their wave (work ~ slots^2).  A few lanes
     // far above the rest (mixed compositions at bin boundaries) are cheaper in a sorted list
-    // stage than as a drag on 64 lanes.
-    for (int round = 0; round < 6; ++round) {
+    // stage than as a drag on 64 lanes.  (Matrix mode only: the list stage's lanes are sorted by table size
+    // already, and which pairs it runs must not depend on the order the list was filled in -- the stage
+    // counters are then the same in every run.)
+    for (int round = 0; round < (RESOLVE ? 0 : 6); ++round) {
         const int next = wave_max_u8(n_cells < nmax ? n_cells : 0);
         const int m = __popcll(__ballot(n_cells == nmax));
         if (next == 0 || nmax * nmax - next * next <= kDragCost * m) break;   // wave-uniform

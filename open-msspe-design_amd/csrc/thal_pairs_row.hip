@@ -39,31 +39,13 @@
 // those of thal_pairs_int.hip; a pair this kernel does not answer goes to the same hand-over list.
 #include "int_core.hpp"
 
-// MSSPE_KO: knock-out switches for timing experiments (tools/variant_build.sh); results are WRONG when set.
-//   1: no tie masks   2: no cell-side select   4: no work after the scan   8: no scan
-#ifndef MSSPE_KO
-#define MSSPE_KO 0
-#endif
-#ifndef MSSPE_ROW_ARGS_LDS
-#define MSSPE_ROW_ARGS_LDS 0
-#endif
-#ifndef MSSPE_ROW_SATSUB
-#define MSSPE_ROW_SATSUB 0
-#endif
-#ifndef MSSPE_ROW_PIPELINE
-#define MSSPE_ROW_PIPELINE 0
-#endif
-#ifndef MSSPE_ROW_THREADS
-#define MSSPE_ROW_THREADS 768
-#define MSSPE_ROW_SLOTS 52
-#endif
 
 namespace msspe {
 
 namespace {
 
 constexpr int kRowK = 13;                        // longest oligo of this kernel
-constexpr int kRowThreads = MSSPE_ROW_THREADS, kRowSlots = MSSPE_ROW_SLOTS;
+constexpr int kRowThreads = 768, kRowSlots = 52;   // three waves per SIMD; 52 stored cells per pair
 constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. 11
 constexpr int kRowA = 772;                       // stride of l2: 4 * 14 * 13 = 728 entries used, = 4 (mod 64)
 constexpr int kRowTEntries = kRowL2 * kRowA;
@@ -87,29 +69,17 @@ static_assert((long long)IntTables::kReach + kRowU + IntTables::kReach + kRowD <
               "largest candidate (valid loop + void cell side + reachable predecessor) must stay a finite double");
 static_assert(kRowU - IntTables::kReach >= IntTables::kValid, "a void entry stays void");
 static_assert((long long)kRowU + kNoY + kRowD < 0x7fffffffLL, "table entries are int32");
-#ifndef MSSPE_ROW_F64MIN
-#define MSSPE_ROW_F64MIN 1
-#endif
-// MSSPE_ROW_OOB: a predecessor that is not up-left of the cell makes the 17-bit address field wrap to at least
+// No address clamp: a predecessor that is not up-left of the cell makes the 17-bit address field wrap to at least
 // kRowWrapMin; with the table placed so that those addresses lie beyond the block's LDS allocation the read
 // returns 0 (gfx950: every ds_read at or beyond the allocation, rounded up to 1,280 bytes, reads 0;
-// tools/lds_oob_probe.hip, checked again by pairs_row_lds_reads_zero() when an engine is made), and 0 is made
+// tools/lds_oob_probe.hip, checked again by pairs_row_lds_reads_zero() when an engine is made -- a device that
+// fails it, and a context with option row_oob = 0, runs the general integer kernel instead), and 0 is made
 // to mean "not available": every table entry carries - kRowZero and every slot value + kRowZero.  That saves
-// the unsigned min that clamped the address in every visit.  0: the clamped address of before.
-#ifndef MSSPE_ROW_OOB
-#define MSSPE_ROW_OOB 1
-#endif
-#if MSSPE_ROW_OOB
+// the unsigned min that clamped the address in every visit.
 constexpr int kRowZero = kRowU + kNoY + kRowD;   // the stored pattern of "not available" before the shift: now 0
 static_assert((long long)IntTables::kReach + kRowZero < 0x7fffffffLL, "slot values + kRowZero are int32");
 static_assert(-(long long)IntTables::kReach + kRowD - kRowZero > -0x7fffffffLL, "table entries - kRowZero are int32");
-#else
-constexpr int kRowZero = 0;
-#endif
-#ifndef MSSPE_ROW_SEG
-#define MSSPE_ROW_SEG 256
-#endif
-constexpr int kSegGroups = MSSPE_ROW_SEG;        // column groups (of 64) per work item
+constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
 // slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
 //             bits 14..0   h + kHBias
 // an empty slot: K one beyond the largest real one (12 * 772 + 4 * 12 + 3), i.e. beyond every cell's minuend, so
@@ -123,7 +93,7 @@ constexpr int kRowWrapMin = 4 * ((1 << 15) - 769 - kEmptyRowK) < (1 << 17) - 4 *
                                 ? 4 * ((1 << 15) - 769 - kEmptyRowK) : (1 << 17) - 4 * (kEmptyRowK - 3);
 
 // Order matters.  LDS instructions take a 16-bit immediate offset, so what is addressed as "lane + constant" or
-// "table + index" lives in the first 64 KB and needs no address arithmetic; and (MSSPE_ROW_OOB) T sits so far
+// "table + index" lives in the first 64 KB and needs no address arithmetic; and T sits so far
 // back that its wrapped addresses fall off the end of the allocation (static_asserts below the struct).
 constexpr int kPredLo = 24;   // rows of the predecessor bytes in front of T (the row number is a scalar: no cost)
 struct SharedRow {
@@ -143,10 +113,6 @@ struct SharedRow {
     unsigned char pred_lo[kPredLo][kRowThreads];
     unsigned next_group;
     int item;
-    // The kernel's arguments (experiment MSSPE_ROW_ARGS_LDS: read from here at the point of use they have no
-    // live range across the DP; measured: scratch write-back 5.1 -> 0.9 GB per launch, but the launch takes
-    // 99 ms instead of 63, the values arriving in vector registers; left off)
-    IntArgs args;
     int T[kRowTEntries + 4];            // [l2 * 772 + (14 i + (i - ii)) * 4 + (3 - n2)]; entry kRowTEntries: not available
     unsigned char pred_hi[kRowSlots + 1 - kPredLo][kRowThreads];   // + 1: the row the last row of a full table writes (never read)
     unsigned short path[kPathMax][kRowThreads];
@@ -155,12 +121,10 @@ struct SharedRow {
         return slot < kPredLo ? pred_lo[slot][tid] : pred_hi[slot - kPredLo][tid];
     }
 };
-#if MSSPE_ROW_OOB
 static_assert(offsetof(SharedRow, T) <= 65532, "T is addressed with an immediate offset");
 static_assert(offsetof(SharedRow, T) + kRowWrapMin >= (sizeof(SharedRow) + 1279) / 1280 * 1280,
               "wrapped table addresses must lie beyond the block's LDS allocation (granule: 1,280 bytes)");
 static_assert(kRowTBytes <= kRowWrapMin, "valid addresses stay inside the table");
-#endif
 static_assert(sizeof(SharedRow) <= 160 * 1024, "one block per CU");
 
 struct KParts {
@@ -203,66 +167,32 @@ struct RCell {
 };
 
 // Table address (byte offset) of predecessor word W seen from the cell with minuend C; a predecessor that
-// is not up-left of the cell lands on a "not available" entry.
+// is not up-left of the cell lands on a "not available" entry.  (The clamped form: used once per cell, for the
+// winner's enthalpy; the scan itself uses scan_index().)
 __device__ __forceinline__ unsigned row_index(unsigned C, unsigned W)
 {
-#if MSSPE_ROW_SATSUB
-    return __builtin_elementwise_sub_sat(C, W) >> 15;   // C < W <=> the column difference is negative: entry 0
-#else
     return min((C - W) >> 15, (unsigned)kRowTBytes);
-#endif
 }
 
 // Running minimum of a scan (all values carry + kRowD): GW = (value : slot word) as one double, G2 = second
 // smallest value so far (two candidates tie for the minimum iff G2 == the minimum at the end).
 struct RowBest {
-#if MSSPE_ROW_F64MIN
     double GW;
-#else
-    int G, W;
-#endif
     int G2;
 };
-__device__ __forceinline__ int best_g(const RowBest &b)
-{
-#if MSSPE_ROW_F64MIN
-    return __double2hiint(b.GW);
-#else
-    return b.G;
-#endif
-}
-__device__ __forceinline__ int best_w(const RowBest &b)
-{
-#if MSSPE_ROW_F64MIN
-    return __double2loint(b.GW);
-#else
-    return b.W;
-#endif
-}
+__device__ __forceinline__ int best_g(const RowBest &b) { return __double2hiint(b.GW); }
+__device__ __forceinline__ int best_w(const RowBest &b) { return __double2loint(b.GW); }
 __device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
 {
-    if (!(MSSPE_KO & 1)) b.G2 = med3_i32(best_g(b), b.G2, cand);   // second smallest so far
-#if MSSPE_ROW_F64MIN
+    b.G2 = med3_i32(best_g(b), b.G2, cand);   // second smallest so far
     const double cd = __hiloint2double(cand, Wp);
     // (asm: fmin() would canonicalise its operands first; both are normal numbers here by construction, and
     //  idle lanes, whose patterns may be anything, publish nothing)
     asm("v_min_f64 %0, %1, %2" : "=v"(b.GW) : "v"(b.GW), "v"(cd));
-#else
-    const bool better = cand < b.G;
-    b.G = min(cand, b.G);
-    b.W = better ? Wp : b.W;
-#endif
 }
 
-// the scan's address: no clamp with MSSPE_ROW_OOB (a wrapped address reads 0 = not available)
-__device__ __forceinline__ unsigned scan_index(unsigned C, unsigned W)
-{
-#if MSSPE_ROW_OOB
-    return (C - W) >> 15;
-#else
-    return row_index(C, W);
-#endif
-}
+// the scan's address: no clamp (a wrapped address lies beyond the allocation and reads 0 = not available)
+__device__ __forceinline__ unsigned scan_index(unsigned C, unsigned W) { return (C - W) >> 15; }
 
 // The table addresses and the (still outstanding) table values of one chunk of slots.
 struct ChunkLoad {
@@ -282,30 +212,21 @@ __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, con
 
 // All slots below `upto` as predecessors of the cell, kC at a time; chunks at or above near_from (the
 // row above the cell) also catch the cell (i-1, j-1).  The chunks are unrolled with compile-time register
-// numbers and left through a wave-uniform branch.  Software pipeline: the gathers of chunk PC + 1 are
-// issued before chunk PC is consumed, so that a wave does not park behind every group of gathers (with
-// three waves per SIMD and a third of all instructions scalar, waiting, not issue, was the limit).
+// numbers and left through a wave-uniform branch.
 template <int NS, int PC = 0>
 __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int near_from, const char *T,
-                                              const RCell &c, RowBest &best, IBest &stk, ScanMasks &m,
-                                              const ChunkLoad &cur)
+                                              const RCell &c, RowBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC * kC < NS) {
         if (PC * kC < upto) {   // wave-uniform
-            ChunkLoad nxt;
-#if MSSPE_ROW_PIPELINE
-            if constexpr ((PC + 1) * kC < NS) {
-                if ((PC + 1) * kC < upto) chunk_issue<NS, PC + 1>(MSSPE_TAB_ARGS, T, c, nxt);   // wave-uniform
-            }
-#else
-            chunk_issue<NS, PC>(MSSPE_TAB_ARGS, T, c, const_cast<ChunkLoad &>(cur));
-#endif
+            ChunkLoad cur;
+            chunk_issue<NS, PC>(MSSPE_TAB_ARGS, T, c, cur);
             if (PC * kC + kC <= near_from) {   // wave-uniform: slots of rows i-2 and above
                 asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS);
+                    const int y = cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS;
                     const int cand = cur.t[e] + y + Gp;   // unavailable: kRowU + ..., never below the minimum <= kValid (all + kRowD)
                     take_min(best, cand, Wp);
                 }
@@ -314,7 +235,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = (MSSPE_KO & 2) ? c.yTS : (cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS);
+                    const int y = cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS;
                     const int cand = cur.t[e] + y + Gp;
                     take_min(best, cand, Wp);
                     const bool isstk = cur.idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
@@ -323,7 +244,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
                     m.stHave |= __builtin_amdgcn_ballot_w64(isstk);
                 }
             }
-            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, near_from, T, c, best, stk, m, nxt);
+            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, near_from, T, c, best, stk, m);
         }
     }
 }
@@ -335,7 +256,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
                                                   bool decisions_only)
 {
-    v32i Ga = kRowZero, Wa = kEmptyRowW;   // slot values carry + kRowZero (MSSPE_ROW_OOB)
+    v32i Ga = kRowZero, Wa = kEmptyRowW;   // slot values carry + kRowZero
     typename TabTypes<NS>::B Gb = kRowZero, Wb = kEmptyRowW;
     typename TabTypes<NS>::C Gc = kRowZero, Wc = kEmptyRowW;
     int defer = 0;
@@ -379,23 +300,14 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         // ---- all earlier slots as predecessors
         RowBest rb;
         IBest stk;
-#if MSSPE_ROW_F64MIN
         rb.GW = __hiloint2double(IntTables::kValid + kRowD, 0);
-#else
-        rb.G = IntTables::kValid + kRowD;
-        rb.W = 0;
-#endif
         rb.G2 = 0x7fffffff;
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
         // predecessors: every slot of the rows above; row i-1 (where the cell (i-1, j-1) lives) through
         // the code that catches it
-        ChunkLoad first;
-#if MSSPE_ROW_PIPELINE
-        if (row_start > 0) chunk_issue<NS, 0>(MSSPE_TAB_ARGS, (const char *)sh.T, rc, first);   // wave-uniform
-#endif
-        if (!(MSSPE_KO & 8)) scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, rb, stk, sm, first);
+        scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, rb, stk, sm);
         const bool tie = rb.G2 == best_g(rb);   // two loop candidates share the minimum
         RBest best;
         best.G = best_g(rb) - kRowD;
@@ -410,7 +322,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         const int rh = sh.h[b.idxR - kRowGBase], gR = sh.g[b.idxR - kRowGBase], hwc = sh.h[b.wc - kRowGBase], gwc = sh.g[b.wc - kRowGBase];
         const double cq = sh.cq[b.idxR - FastTables::kEndR];
         const int pickG = sh.pick[0][threadIdx.x];
-        if (stHave && !(MSSPE_KO & 4)) {
+        if (stHave) {
             const int h1 = word_h(stk.W) + hwc;
             const int G1 = stk.G + (gwc - kRowZero);
             const double A0 = (double)(h0 + 20 + rh), A1 = (double)(h1 + 20 + rh);
@@ -425,7 +337,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
             }
         }
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
-        if (best.G <= G0 && !(MSSPE_KO & 4)) {
+        if (best.G <= G0) {
             // exact enthalpy of the best candidate: the loop term's from the table that mirrors T
             const unsigned idx = row_index(rc.C, (unsigned)best.W);
             const int th = sh.TH[idx >> 2];
@@ -610,8 +522,6 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
     const int lane = threadIdx.x & 63;
     SeqPair q;
     unsigned rowmask;
-    // (values read from the LDS copy of the arguments are vector registers: what steers control flow is
-    // made a scalar again, or every loop over it becomes a divergent one)
     const int k = __builtin_amdgcn_readfirstlane(a.f.k);
     const int n_all = setup_pair(pa, pb, k, q, rowmask);
     q.s1 = (unsigned)__builtin_amdgcn_readfirstlane((int)q.s1);   // the block's row primer: a scalar
@@ -782,7 +692,7 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
             if (v >= IntTables::kValid) hv = 0;
         }
         if (v >= IntTables::kValid) v = kRowU;
-        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD - kRowZero;   // MSSPE_ROW_OOB: "not available" is 0
+        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD - kRowZero;   // "not available" is 0
         sh.TH[e] = (short)(((hv / 10) << 1) | (needs_y ? 1 : 0));
     }
     if (threadIdx.x < 4) {
@@ -810,7 +720,6 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
     }
     for (int e = threadIdx.x; e < 100; e += kRowThreads)
         sh.cq[e] = 620300.0 * ((a.f.c.init_S + a.f.ft->S[FastTables::kEndR + e]) + a.f.c.RC);
-    if (threadIdx.x == 0) sh.args = a;
     const int lane = threadIdx.x & 63;
     const int ncolg = (a.f.col1 - a.f.col0 + 63) >> 6;
     const int n_seg = (ncolg + kSegGroups - 1) / kSegGroups;
@@ -848,11 +757,7 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
             const bool inside = cq < a.f.col1;
             const uint64_t pb = a.f.cols_sorted[inside ? cq : a.f.col0];
             const int col = (int)a.f.perm[inside ? cq : a.f.col0];
-#if MSSPE_ROW_ARGS_LDS
-            wave_pairs_row<NS>(sh, sh.args, row, col, pa, pb, inside);
-#else
             wave_pairs_row<NS>(sh, a, row, col, pa, pb, inside);
-#endif
         }
         __syncthreads();   // every wave is done with the table (and with sh.item) before the next item
     }
@@ -863,13 +768,40 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
 int pairs_row_max_k() { return kRowK; }
 
 namespace {
-// Reads the LDS addresses the row kernel's wrapped table addresses can produce, from a block with the row
-// kernel's allocation, filled with ones: every read must return 0.
-__global__ void __launch_bounds__(256) k_lds_probe(unsigned lo, unsigned hi, unsigned *nonzero)
+// The probe behind pairs_row_lds_reads_zero(), two launches.
+//   k_lds_paint: one block per CU with the largest LDS allocation a block can have writes a non-zero pattern
+//       over the CU's whole LDS (the blocks wait for each other, bounded, so that they spread over all CUs).
+//   k_lds_probe: blocks with the ROW KERNEL'S OWN static allocation (the same `__shared__ SharedRow`) paint
+//       their allocation as well and read every address a wrapped table address can produce.  What lies beyond
+//       the allocation but inside the CU's LDS still holds k_lds_paint's pattern, so a device that did not
+//       bounds-check the read would return it; every read must return 0.
+constexpr unsigned kLdsPaintBytes = 160 * 1024;
+__device__ __forceinline__ void wait_for_peers(unsigned *arrived, unsigned want)
 {
-    extern __shared__ unsigned fill[];
+    // bounded: the point is to keep the block on its CU while the others are placed, not a barrier anyone
+    // depends on (a busy device may not hold all the blocks at once)
+    if (threadIdx.x == 0) {
+        atomicAdd(arrived, 1u);
+        const unsigned long long t0 = wall_clock64();   // 100 MHz
+        while (atomicAdd(arrived, 0u) < want && wall_clock64() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_lds_paint(unsigned *arrived)
+{
+    extern __shared__ unsigned paint[];
+    for (unsigned e = threadIdx.x; e < kLdsPaintBytes / 4; e += blockDim.x) paint[e] = 0xa5a5a5a5u;
+    __syncthreads();
+    wait_for_peers(arrived, gridDim.x);
+    if (paint[(threadIdx.x * 97u) % (kLdsPaintBytes / 4)] != 0xa5a5a5a5u) __builtin_trap();   // keeps the stores
+}
+__global__ void __launch_bounds__(kRowThreads) k_lds_probe(unsigned lo, unsigned hi, unsigned *arrived, unsigned *nonzero)
+{
+    __shared__ SharedRow sh;
+    unsigned *fill = (unsigned *)&sh;
     for (unsigned e = threadIdx.x; e < sizeof(SharedRow) / 4; e += blockDim.x) fill[e] = 0xffffffffu;
     __syncthreads();
+    wait_for_peers(arrived, gridDim.x);
     unsigned bad = 0;
     for (unsigned addr = lo + 4u * threadIdx.x; addr < hi; addr += 4u * blockDim.x) {
         unsigned v;
@@ -877,43 +809,45 @@ __global__ void __launch_bounds__(256) k_lds_probe(unsigned lo, unsigned hi, uns
         bad |= v;
     }
     if (bad) atomicOr(nonzero, 1u);
+    if (fill[threadIdx.x] != 0xffffffffu) atomicOr(nonzero, 2u);
 }
 }  // namespace
 
-// MSSPE_ROW_OOB rests on this (see the macro): checked once per engine, on the engine's device.
-hipError_t pairs_row_lds_reads_zero(hipStream_t stream, bool *ok)
+// The row kernel has no address clamp (see kRowZero): checked once per engine, on the engine's device.
+hipError_t pairs_row_lds_reads_zero(hipStream_t stream, int n_cu, bool *ok)
 {
-    *ok = true;
-#if MSSPE_ROW_OOB
-    {   // the kernel's real LDS size (the static_asserts speak for SharedRow; a compiler could add to it)
-        hipFuncAttributes fa;
-        const hipError_t ea = hipFuncGetAttributes(&fa, (const void *)k_pairs_row<kRowSlots>);
+    *ok = false;
+    {   // the kernel's real LDS size (the static_asserts speak for SharedRow; a compiler could add to it), and the
+        // probe's must be the same
+        hipFuncAttributes fa, fp;
+        hipError_t ea = hipFuncGetAttributes(&fa, (const void *)k_pairs_row<kRowSlots>);
+        if (ea == hipSuccess) ea = hipFuncGetAttributes(&fp, (const void *)k_lds_probe);
         if (ea != hipSuccess) return ea;
-        if (offsetof(SharedRow, T) + (size_t)kRowWrapMin < (fa.sharedSizeBytes + 1279) / 1280 * 1280) {
-            *ok = false;
-            return hipSuccess;
-        }
+        if (fa.sharedSizeBytes != fp.sharedSizeBytes) return hipSuccess;
+        if (offsetof(SharedRow, T) + (size_t)kRowWrapMin < (fa.sharedSizeBytes + 1279) / 1280 * 1280) return hipSuccess;
     }
-    unsigned *d_flag = nullptr, h_flag = 1;
-    hipError_t e = hipMalloc((void **)&d_flag, sizeof(unsigned));
+    unsigned *d_flag = nullptr, h_flag[3] = {0, 0, 1};
+    hipError_t e = hipMalloc((void **)&d_flag, 3 * sizeof(unsigned));
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(d_flag, 0, sizeof(unsigned), stream);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_lds_probe, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)sizeof(SharedRow));
+    e = hipMemsetAsync(d_flag, 0, 3 * sizeof(unsigned), stream);
     if (e == hipSuccess) {
         const unsigned lo = (unsigned)offsetof(SharedRow, T) + (unsigned)kRowWrapMin;
         const unsigned hi = (unsigned)offsetof(SharedRow, T) + (1u << 17);
-        hipLaunchKernelGGL(k_lds_probe, dim3(1), dim3(256), sizeof(SharedRow), stream, lo, hi, d_flag);
+        const int grid = n_cu > 0 ? n_cu : 256;
+        // (a runtime that refuses a block of the CU's whole LDS leaves the probe without the painted background:
+        //  what it reads beyond its allocation is then whatever earlier kernels left there)
+        if (hipFuncSetAttribute((const void *)k_lds_paint, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsPaintBytes) == hipSuccess)
+            hipLaunchKernelGGL(k_lds_paint, dim3(grid), dim3(256), kLdsPaintBytes, stream, d_flag);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_lds_probe, dim3(grid), dim3(kRowThreads), 0, stream, lo, hi, d_flag + 1, d_flag + 2);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_flag);
     if (e != hipSuccess) return e;
-    *ok = h_flag == 0;
-#else
-    (void)stream;
-#endif
+    *ok = h_flag[2] == 0;
     return hipSuccess;
 }
 

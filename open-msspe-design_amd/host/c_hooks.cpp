@@ -9,7 +9,10 @@ using namespace od_msspe;
 namespace {
 int emit(const std::string &s, char *out, size_t cap)
 {
-    if (s.size() + 1 > cap) return -1;
+    if (s.size() + 1 > cap) {   // -3: the caller's buffer is too small (and says so: it is left an empty string)
+        if (cap) out[0] = '\0';
+        return -3;
+    }
     std::memcpy(out, s.c_str(), s.size() + 1);
     return (int)s.size();
 }

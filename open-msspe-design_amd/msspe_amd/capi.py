@@ -13,7 +13,7 @@ STATUS = {0: "MSSPE_OK", 1: "MSSPE_ERR_ARG", 2: "MSSPE_ERR_K", 3: "MSSPE_ERR_TAB
 # every symbol include/msspe_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "msspe_chem_ntthal_defaults", "msspe_chem_primer3_defaults", "msspe_create", "msspe_destroy",
-    "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_set_stream", "msspe_reset_stream",
+    "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_get_info", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
     "msspe_cross_dimer_edges_dev", "msspe_cross_dimer_edges",
@@ -62,7 +62,7 @@ _lib_override: Path | None = None
 
 
 def use_library(path) -> None:
-    """Development aid (tools/variant_build.sh): load another build of the library; call before the
+    """Development aid (tools/variant_build_file.sh): load another build of the library; call before the
     first Engine is created."""
     global _lib_override
     _lib_override = Path(path)
@@ -92,6 +92,7 @@ def load_library() -> C.CDLL:
     L.msspe_destroy.argtypes = [vp]
     L.msspe_set_stream.argtypes = [vp, vp]
     L.msspe_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.msspe_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
     L.msspe_reset_stream.argtypes = [vp]
     L.msspe_synchronize.argtypes = [vp]
     L.msspe_pack_oligos.argtypes = [C.c_char_p, C.c_int, C.c_int, u64p]
@@ -217,6 +218,12 @@ class Engine:
         """Engine option (include/msspe_hip.h msspe_set_option); the library never reads the environment."""
         self._check(self.L.msspe_set_option(self.ptr, key.encode(), str(value).encode()))
 
+    def info(self, key: str) -> int:
+        """Facts about the device and the kernels the context will run (include/msspe_hip.h msspe_get_info)."""
+        v = C.c_longlong(0)
+        self._check(self.L.msspe_get_info(self.ptr, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def reset_stream(self):
         self._check(self.L.msspe_reset_stream(self.ptr))
 
@@ -329,6 +336,13 @@ class Engine:
         self._check(self.L.msspe_oligo_stats(self.ptr, buf, n, k, C.byref(chem),
                                              *[out[x].ctypes.data for x in out]))
         return out
+
+    def oligo_stats_dev(self, d_pool: int, n: int, k: int, chem: Chem, d_tm: int = 0, d_gc: int = 0,
+                        d_self_any: int = 0, d_self_end: int = 0, d_hairpin: int = 0):
+        """Device-pointer call (raw addresses of n packed oligos and of n doubles per requested statistic,
+        0 = not wanted); asynchronous on the context's stream."""
+        self._check(self.L.msspe_oligo_stats_dev(self.ptr, C.c_void_p(d_pool), n, k, C.byref(chem),
+                                                 *[C.c_void_p(x) for x in (d_tm, d_gc, d_self_any, d_self_end, d_hairpin)]))
 
     # ---- stage A ---------------------------------------------------------------------------
     def kmer_candidates(self, seqs: np.ndarray, opt: KmerOpt, direction: int,

@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import capi
-from .distributed import shard_bounds
+from .distributed import all_reduce, shard_bounds
 
 PKG = Path(__file__).resolve().parent.parent
 
@@ -39,10 +39,17 @@ def _host():
     return C.CDLL(str(PKG / "libod_msspe_host.so"))
 
 
-def _call(fn, *args, cap=1 << 24):
-    buf = C.create_string_buffer(cap)
-    rc = fn(*args, buf, cap)
-    return rc, buf.value.decode()
+def _call(fn, *args):
+    """A host-layer text call: (status, text).  The output buffer is sized from the inputs (none of these calls
+    returns more than it was given, plus formatting) and grown while the library reports that it was too small
+    (c_hooks.cpp emit(): status -3)."""
+    cap = max(1 << 16, 2 * sum(len(x) for x in args if isinstance(x, (bytes, bytearray))) + (1 << 12))
+    while True:
+        buf = C.create_string_buffer(cap)
+        rc = fn(*args, buf, cap)
+        if rc != -3 or cap >= (1 << 34):
+            return rc, buf.value.decode()
+        cap *= 4
 
 
 def parse_args(argv=None):
@@ -104,6 +111,8 @@ def main(argv=None) -> int:
     payload = [None]
     if rank == 0:
         rc, rec_text = _call(host.odm_to_records, Path(a.input).read_bytes())
+        if rc == -3:
+            raise SystemExit("pipeline_ranks: record buffer too small for the input")
         if rc < 0 or not rec_text:
             raise SystemExit("No sequences found in the input file")
         records = [ln.split("\t") for ln in rec_text.splitlines()]
@@ -137,9 +146,12 @@ def main(argv=None) -> int:
                 for q, key in enumerate(("tm", "gc", "self_any", "self_end", "hairpin")):
                     mine[q, r0:r1] = st[key]
             if world > 1:
-                t = torch.from_numpy(mine)
-                dist.all_reduce(t)          # disjoint slices: the sum is the concatenation
-                mine = t.numpy()
+                # disjoint slices: the sum is the concatenation.  Reduced on the device: the RCCL process group
+                # has no CPU backend (a host tensor would raise "No backend type associated with device type cpu");
+                # under gloo the helper stages the device tensor through the host
+                t = torch.from_numpy(mine).to(dev)
+                all_reduce(t)
+                mine = t.cpu().numpy()
             out = mine
         rnd = capi.round_fixed_f32     # the text primer3_core prints, read back as f32 (primer.rs:94-106)
         return {"tm": np.array([rnd(x, 3) for x in out[0]], dtype=np.float32),

@@ -1,10 +1,17 @@
 """BASELINE.json's configurations at their full sizes, on the GPU, through the C ABI / the CLI.
 
+configs[0]  10 pre-aligned ~29.9 kb genomes, --kmer-size 13 --check-hairpin true (config.rs:21,101): the whole CLI
+            run against the restated pipeline.
 configs[1]  1,000 synthetic aligned 30 kb genomes, Tm + hairpin + self-dimer filters: the whole CLI run
             against the oracle-based restatement of main.rs (CSV + coverage report byte for byte).
 configs[2]  10,000 x 30 kb: stage A's first winners re-counted on the CPU, independently of the oracle's
             restatement (which needs minutes at this size): each winner's frequency is the number of live
             segments holding it AND the maximum over all k-mers of the live segments (main.rs:285-329).
+configs[3]  the 1,048,576-candidate pool: a slice of the row block rank 3 of 8 owns and the pool's last rows, against
+            all 2^20 columns (row x column products beyond 2^32, column indices up to 2^20 - 1): counts are the
+            popcounts of the bitmap rows and sampled rows equal the oracle's decisions (delta_g.rs:61-81).
+configs[4]  5,000 x 1.8 kb (the influenza-A HA shape), all filters, --max-iterations 1000 (config.rs:38): the CLI
+            and the three-rank harness against the restated pipeline.
 headline    65,536-primer pool, 4.29e9 ordered pairs: counts are the popcounts of the bitmap rows, and 32
             sampled rows equal the oracle's decisions.
 """
@@ -42,6 +49,99 @@ def test_config1_1000_genomes_cli_equals_the_restated_pipeline(m, tmp_path):
     assert csv.read_text() == want_csv
     assert buf.value.decode() == want_report
     assert want_csv.count("\n") > 100          # hundreds of primers survive the filters
+
+
+def _run_cli(m, args, cap=1 << 22):
+    m.load_library()
+    host = C.CDLL(str(ROOT / "open-msspe-design_amd" / "libod_msspe_host.so"))
+    arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    buf = C.create_string_buffer(cap)
+    rc = host.odm_run_cli(len(args), arr, buf, cap)
+    return rc, buf.value.decode()
+
+
+def test_config0_ten_genomes_kmer13_hairpin_cli_equals_the_restated_pipeline(m, tmp_path):
+    import ref_pipeline
+    g = m.synth.aligned_genomes(10, 29903, seed=29903)          # SARS-CoV-2's length; no real data offline
+    fasta = "".join(f">MN908947.{i} synthetic\n{bytes(r).decode()}\n" for i, r in enumerate(g))
+    fa, csv = tmp_path / "in.fa", tmp_path / "out.csv"
+    fa.write_text(fasta)
+    rc, report = _run_cli(m, ["od-msspe-hip", "-i", str(fa), "-o", str(csv), "--do-align", "false",
+                              "--kmer-size", "13", "--check-hairpin", "true"])
+    assert rc == 0, report
+    want_csv, want_report, info = ref_pipeline.run(fasta, kmer_size=13, check_hairpin=True)
+    assert csv.read_text() == want_csv
+    assert report == want_report
+    assert want_csv.count("\n") > 50 and sum(info["candidates"].values()) > 100
+    # a bare --check-hairpin is a usage error in the reference (string booleans, config.rs:65-140)
+    rc, _ = _run_cli(m, ["od-msspe-hip", "-i", str(fa), "-o", str(csv), "--do-align", "false", "--check-hairpin"])
+    assert rc == 2
+
+
+def test_config3_pool_1m_row_blocks_against_all_columns(m, oracle, oracle_tables):
+    import torch
+    from msspe_amd.distributed import shard_bounds
+    n, k = 1 << 20, 13
+    pool_ascii = m.synth.random_pool(n, k)
+    d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
+    words = n // 64
+    r3 = shard_bounds(n, 8, 3)[0]                       # first row of rank 3's block (of 8)
+    blocks = [(r3, r3 + 2048), (n - 96, n)]             # 2.1e9 checks + the pool's last rows
+    eng = m.Engine(0)
+    rng = np.random.default_rng(1 << 20)
+    try:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        for (r0, r1), n_samples in zip(blocks, (14, 14)):
+            d_rc = torch.zeros(n, dtype=torch.int32, device="cuda")
+            d_bm = torch.zeros((r1 - r0, words), dtype=torch.int64, device="cuda")
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, k, m.Chem.ntthal(), -9000.0, (r0, r1), (0, n),
+                                d_rc.data_ptr(), d_bm.data_ptr())
+            torch.cuda.synchronize()
+            assert eng.last_overflow_pairs() > 0
+            rc = d_rc.cpu().numpy().astype(np.int64)
+            bm = d_bm.cpu().numpy().view(np.uint64)
+            assert rc[:r0].sum() == 0 and rc[r1:].sum() == 0           # only the block's rows are counted
+            np.testing.assert_array_equal(np.bitwise_count(bm).sum(axis=1).astype(np.int64), rc[r0:r1])
+            assert 0.004 < rc.sum() / (float(r1 - r0) * n) < 0.007     # 0.54 % of random 13-mer pairs conflict
+            # (the oracle runs one thread per row: a run of consecutive rows costs what one row costs)
+            s0 = int(rng.integers(r0, r1 - n_samples + 1))
+            _, _, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii, rows=(s0, s0 + n_samples), want_dg=False)
+            got = np.unpackbits(bm[s0 - r0:s0 - r0 + n_samples].view(np.uint8), axis=1, bitorder="little")[:, :n]
+            np.testing.assert_array_equal(got, cf)
+            del d_bm
+        stats = eng.pair_stage_stats()
+        assert stats["replay_mismatch"] == 0 and stats["list"]["replay_mismatch"] == 0
+    finally:
+        eng.close()
+
+
+def test_config4_5000_ha_segments_cli_and_three_ranks_equal_the_restated_pipeline(m, tmp_path):
+    import os
+    import subprocess
+    import sys
+    import ref_pipeline
+    # eight clades of 625 rows, each around its own random ancestor (HA subtypes differ by tens of per cent; rows of
+    # one clade by 2 %): the greedy loop runs for hundreds of iterations instead of stopping after one clade's words
+    g = np.concatenate([m.synth.aligned_genomes(625, 1800, seed=40 + c) for c in range(8)])
+    fasta = "".join(f">HA_{i} synthetic\n{bytes(r).decode()}\n" for i, r in enumerate(g))
+    fa, csv, csv3 = tmp_path / "in.fa", tmp_path / "cli.csv", tmp_path / "ranks.csv"
+    fa.write_text(fasta)
+    flags = ["--max-iterations", "1000", "--check-hairpin", "true", "--check-self-dimers", "true",
+             "--check-cross-dimers", "true"]
+    rc, report = _run_cli(m, ["od-msspe-hip", "-i", str(fa), "-o", str(csv), "--do-align", "false"] + flags)
+    assert rc == 0, report
+    want_csv, want_report, info = ref_pipeline.run(fasta, max_iterations=1000)
+    assert csv.read_text() == want_csv
+    assert report == want_report
+    assert want_csv.count("\n") > 150 and sum(info["candidates"].values()) > 200
+    env = dict(os.environ, PYTHONPATH=str(ROOT / "open-msspe-design_amd"), MSSPE_BENCH_BACKEND="gloo", MSSPE_BENCH_DEVICE="0")
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "msspe_amd.pipeline_ranks", "-i", str(fa), "-o", str(csv3)] + flags
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert csv3.read_text() == want_csv
 
 
 def _head_window_keys(genomes: np.ndarray, seg=500, stride=250, win=50, k=13):

@@ -380,9 +380,37 @@ def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypat
     for key in ("dg", "tm", "bitmap", "row_conflicts"):
         np.testing.assert_array_equal(a[key], b[key])
         np.testing.assert_array_equal(a[key], c[key])
-    # (how many pairs each first stage answers itself differs: the row kernel pads a wave's rows to its
-    # widest lane, and in a pool this small every wave mixes compositions; both see ties)
+    # Which pairs a first stage answers itself differs between the two kernels (the row kernel pads a wave's rows
+    # to its widest lane, the general one counts a lane's own cells), so their own counters differ.  What
+    # the integers cannot settle is a property of the pair, though: every pair with such a reason reaches the
+    # list stage whichever kernel ran first, so the list stage's counters must agree exactly ...
     assert stats_general["deferred"] > 0 and stats_general["replay_mismatch"] == 0
+    assert stats["list"] == stats_general["list"] and stats["needed_f64"] == stats_general["needed_f64"]
+    # ... and a pair both first stages ran and handed on was handed on for the same reasons (pick_tie, loop_tie,
+    # path_tie, rejected_min, ...: bit for bit)
+    small = pool[:120]
+    eng.pair_stage_stats()
+    eng.cross_dimer(small, chem, -9000.0, want_dg=True)
+    by_row = {(r, c): bits for r, c, bits in eng.pair_stage_samples()}
+    eng.pair_stage_stats()
+    eng.set_option("pair_kernel", "int")
+    try:
+        eng.cross_dimer(small, chem, -9000.0, want_dg=True)
+        by_int = {(r, c): bits for r, c, bits in eng.pair_stage_samples()}
+        eng.pair_stage_stats()
+    finally:
+        eng.set_option("pair_kernel", "auto")
+    both = set(by_row) & set(by_int)
+    assert len(by_row) < 1024 and len(by_int) < 1024 and len(both) > 20
+    assert all(by_row[pr] == by_int[pr] for pr in both)
+    # identical runs give identical counters (the columns are grouped by a stable sort: the lane a pair runs
+    # in, and with it every hand-over decision, is the same every time)
+    eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+    assert eng.pair_stage_stats() == stats
+    eng.cross_dimer(pool, chem, -9000.0)
+    once = eng.pair_stage_stats()
+    eng.cross_dimer(pool, chem, -9000.0)
+    assert eng.pair_stage_stats() == once
     n2 = len(pool) ** 2
     assert 0 < stats["deferred"] < 0.06 * n2                  # retried in list mode
     assert 0 < stats["needed_f64"] < 0.01 * n2                # what only the f64 kernels can answer
@@ -399,6 +427,67 @@ def test_integer_stage_equals_f64_stage(eng, m, oracle, oracle_tables, monkeypat
             assert np.isinf(a["dg"][r, c])
         else:
             assert a["dg"][r, c] == res.dG and a["tm"][r, c] == res.t
+
+
+def test_row_kernel_probe_and_its_fallback(eng, m):
+    """The row-specialised first stage reads LDS beyond its allocation and takes the 0 gfx950 returns there for
+    "not available" (thal_pairs_row.hip).  The per-engine probe must find that behaviour on this device (or the
+    headline numbers are the general kernel's), and the fallback it guards -- option row_oob = 0, the same
+    branch a failed probe takes -- must give the same doubles and decisions and be the general integer kernel
+    to the last counter."""
+    assert eng.info("lds_reads_zero") == 1 and eng.info("row_kernel") == 1
+    assert eng.info("n_cu") >= 64
+    pool = m.synth.pool_strings(m.synth.random_pool(600, 13, seed=4242))
+    chem = m.Chem.ntthal()
+    eng.pair_stage_stats()
+    a = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+    stats_row = eng.pair_stage_stats()
+    fast = eng.cross_dimer(pool, chem, -9000.0)
+    eng.pair_stage_stats()
+    try:
+        eng.set_option("row_oob", 0)
+        assert eng.info("row_kernel") == 0
+        b = eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+        stats_fallback = eng.pair_stage_stats()
+        fast_b = eng.cross_dimer(pool, chem, -9000.0)
+        eng.pair_stage_stats()
+        eng.set_option("row_oob", 1)
+        eng.set_option("pair_kernel", "int")
+        eng.cross_dimer(pool, chem, -9000.0, want_dg=True, want_tm=True)
+        stats_int = eng.pair_stage_stats()
+    finally:
+        eng.set_option("row_oob", 1)
+        eng.set_option("pair_kernel", "auto")
+    for key in ("dg", "tm", "bitmap", "row_conflicts"):
+        np.testing.assert_array_equal(a[key], b[key])
+    for key in ("bitmap", "row_conflicts"):
+        np.testing.assert_array_equal(fast[key], fast_b[key])
+        np.testing.assert_array_equal(fast[key], a[key])
+    assert stats_fallback == stats_int            # the fallback IS the general integer kernel
+    assert stats_fallback != stats_row            # ... and the default is not
+    with pytest.raises(m.MsspeError):
+        eng.set_option("row_oob", 2)
+    with pytest.raises(m.MsspeError):
+        eng.info("no_such_key")
+
+
+def test_small_fixed_lists_bound_the_launches(eng, m):
+    """option list_cap_log2 below one default launch (2^27 pairs): launches shrink to what a list holds, so a list
+    cannot be overrun whatever share of the pairs is handed on (here: every pair with planes, a pool of two
+    letters whose tables are all oversized)."""
+    pools = [m.synth.pool_strings(m.synth.random_pool(1500, 13, seed=5)),
+             ["".join(np.random.default_rng(s).choice(list("AT"), 13)) for s in range(1300)]]
+    chem = m.Chem.ntthal()
+    for pool in pools:
+        want = eng.cross_dimer(pool, chem, -9000.0)
+        try:
+            eng.set_option("list_cap_log2", 20)          # 2^20 entries < 1500^2 pairs
+            got = eng.cross_dimer(pool, chem, -9000.0)
+            assert eng.last_overflow_pairs() > 0
+        finally:
+            eng.set_option("list_cap_log2", 0)
+        for key in ("bitmap", "row_conflicts"):
+            np.testing.assert_array_equal(got[key], want[key])
 
 
 def _read_bundle(path):
