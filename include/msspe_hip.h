@@ -294,6 +294,47 @@ int msspe_segment_coverage_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, 
 int msspe_device_free(msspe_ctx *ctx, void *device);
 
 
+/* ---- several devices of one node ----------------------------------------------------------
+ *
+ * One process, one context and one host thread per device.  What shards is the reference's N^2 pair loop
+ * (od-msspe/src/delta_g.rs:61-81, called at main.rs:739-752: every ordered pair is independent) and the per-oligo
+ * statistics (od-msspe/src/primer.rs:143-166); stage A's greedy loop is sequential and runs on member 0's context
+ * (msspe_group_member(g, 0) with the msspe_kmer_candidates* calls).
+ *
+ * A screen: every member uploads the slice of the pool it "produced" (contiguous n / N candidates), ONE all-gather
+ * assembles the packed pool on every device, every member screens its rows against all columns, ONE all-reduce
+ * merges the per-primer conflict counts; bitmap rows and edge lists stay with their member until the host call
+ * collects them.  Rows are dealt out in groups of 256, round robin (row r belongs to member (r / 256) mod N), so
+ * that every member gets a sample of the whole pool whatever its order (msspe_group_rows lists a member's rows).
+ * Results are identical to the single-context calls.
+ *
+ * transport: "auto" (NULL) | "rccl" | "device-copy".  "rccl": RCCL over xGMI, librccl.so loaded when the group is
+ * made, needs distinct devices.  "device-copy": device-to-device copies and a summing kernel -- for members that
+ * share a card (a device may be listed more than once: how the tests rehearse N members on one GPU) and where
+ * RCCL cannot be loaded.  auto = rccl for two or more distinct devices if it loads, else device-copy.
+ */
+typedef struct msspe_group msspe_group;
+int msspe_group_create(const int *devices, int n_devices, const char *params_path, const char *transport,
+                       msspe_group **out);
+void msspe_group_destroy(msspe_group *g);
+const char *msspe_group_last_error(const msspe_group *g);
+int msspe_group_size(const msspe_group *g);
+const char *msspe_group_transport(const msspe_group *g);          /* "single" | "rccl" | "device-copy" */
+msspe_ctx *msspe_group_member(msspe_group *g, int member);        /* owned by the group */
+int msspe_group_set_option(msspe_group *g, const char *key, const char *value);   /* msspe_set_option on every member */
+/* pool rows member `member` of a group of n_members screens in a pool of n (ascending).  Host only, no device.
+ * *n_rows_out is set even when capacity is 0 (sizing call); a capacity that is too small: MSSPE_ERR_CAPACITY */
+int msspe_group_rows(int n, int n_members, int member, uint32_t *rows_out, int capacity, int *n_rows_out);
+/* msspe_cross_dimer over the group (host buffers; row_conflicts[n] merged, bitmap[n * ceil(n/64)] optional) */
+int msspe_cross_dimer_group(msspe_group *g, const char *pool_ascii, int n, int k, const msspe_chem *chem,
+                            float dg_threshold, uint32_t *row_conflicts, uint64_t *bitmap);
+/* msspe_cross_dimer_edges over the group: same order, same rounding, same capacity contract */
+int msspe_cross_dimer_edges_group(msspe_group *g, const char *pool_ascii, int n, int k, const msspe_chem *chem,
+                                  float dg_threshold, msspe_edge *edges, uint64_t capacity, uint64_t *count_out);
+/* msspe_oligo_stats over the group (contiguous slices of the oligos, one per member) */
+int msspe_oligo_stats_group(msspe_group *g, const char *pool_ascii, int n, int k, const msspe_chem *chem,
+                            double *tm, double *gc, double *self_any, double *self_end, double *hairpin);
+
 /* ---- text rounding at the reference's process boundary ----------- */
 
 float msspe_round_g_f32(double x);                  /* "%g"   -> f32 (od-msspe/src/delta_g.rs:33-35) */

@@ -9,7 +9,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
        -Wall -Wno-unused-function)
 mkdir -p "$here/build"
 objs=()
-for src in nn_params.cpp capi.cpp kernels_generic.hip thal_hairpin_wave.hip thal_pairs.hip thal_pairs_int.hip thal_pairs_row.hip thal_pairs_split.hip thal_pairs_wave.hip pool_sort.hip kmer_stage.hip; do
+for src in nn_params.cpp capi.cpp kernels_generic.hip thal_hairpin_wave.hip thal_pairs.hip thal_pairs_int.hip thal_pairs_row.hip thal_pairs_split.hip thal_pairs_wave.hip pool_sort.hip kmer_stage.hip group.hip; do
   obj="$here/build/${src%.*}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || -n "$(find . -name '*.hpp' -newer "$obj" -print -quit)" \
         || ../../include/msspe_hip.h -nt "$obj" ]]; then

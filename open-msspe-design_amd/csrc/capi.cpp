@@ -277,6 +277,10 @@ __global__ void k_accumulate_overflow(const uint32_t *count, uint64_t *total, ui
 
 }  // namespace
 
+namespace msspe {
+hipStream_t ctx_stream(msspe_ctx *ctx) { return ctx->stream; }   // group.hip: collectives are enqueued on the members' streams
+}
+
 extern "C" {
 
 const char *msspe_version(void) { return "msspe-hip 0.1.0 (gfx950)"; }

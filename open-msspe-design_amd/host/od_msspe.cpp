@@ -68,6 +68,7 @@ const OptSpec kOpts[] = {
     {"--primer3", "PRIMER3", OptSpec::Str, OFF(primer3)},
     {"--params-path", "MSSPE_PARAMS_PATH", OptSpec::Str, OFF(params_path)},
     {"--device", "MSSPE_DEVICE", OptSpec::Int, OFF(device)},
+    {"--devices", "MSSPE_DEVICES", OptSpec::Str, OFF(devices)},
 };
 #undef OFF
 
@@ -265,7 +266,27 @@ Engine::Engine(int device, const std::string &params_path)
         throw std::runtime_error("msspe_create: " + msg);
     }
 }
-Engine::~Engine() { if (ctx_) msspe_destroy(ctx_); }
+Engine::Engine(const std::vector<int> &devices, const std::string &params_path)
+{
+    const int rc = msspe_group_create(devices.data(), (int)devices.size(), params_path.empty() ? nullptr : params_path.c_str(),
+                                      nullptr, &group_);
+    if (rc) {
+        const std::string msg = group_ ? msspe_group_last_error(group_) : "allocation failed";
+        if (group_) msspe_group_destroy(group_);
+        group_ = nullptr;
+        throw std::runtime_error("msspe_group_create: " + msg);
+    }
+    ctx_ = msspe_group_member(group_, 0);
+}
+Engine::~Engine()
+{
+    if (group_) msspe_group_destroy(group_);   // owns its members
+    else if (ctx_) msspe_destroy(ctx_);
+}
+void Engine::fail_group(int rc) const
+{
+    throw std::runtime_error(std::string("libmsspe_hip status ") + std::to_string(rc) + ": " + msspe_group_last_error(group_));
+}
 void Engine::fail(int rc) const
 {
     throw std::runtime_error(std::string("libmsspe_hip status ") + std::to_string(rc) + ": " +
@@ -353,9 +374,15 @@ std::vector<PrimerInfo> check_primers(Engine &eng, const std::vector<std::string
     std::vector<double> tm((size_t)n), gc((size_t)n), any((size_t)n), end((size_t)n), hp((size_t)n);
     msspe_chem chem;
     msspe_chem_primer3_defaults(&chem);   // primer.rs:125-140 sends only size / Tm bounds
-    const int rc = msspe_oligo_stats(eng.ctx(), flat.data(), n, k, &chem, tm.data(), gc.data(),
-                                     any.data(), end.data(), hp.data());
-    if (rc) eng.fail(rc);
+    if (eng.group()) {   // oligos are independent: a slice per device
+        const int rc = msspe_oligo_stats_group(eng.group(), flat.data(), n, k, &chem, tm.data(), gc.data(), any.data(),
+                                               end.data(), hp.data());
+        if (rc) eng.fail_group(rc);
+    } else {
+        const int rc = msspe_oligo_stats(eng.ctx(), flat.data(), n, k, &chem, tm.data(), gc.data(),
+                                         any.data(), end.data(), hp.data());
+        if (rc) eng.fail(rc);
+    }
     for (int i = 0; i < n; ++i) {
         PrimerInfo p;
         p.id = primers[(size_t)i];
@@ -482,12 +509,19 @@ ConflictGraph run_ntthal(Engine &eng, const std::vector<std::string> &primers,
     // dense n x n bitmap; if the first guess is too small the call says how many there are
     std::vector<msspe_edge> edges((size_t)std::max<uint64_t>(4096, (uint64_t)n * (uint64_t)n / 64));
     uint64_t count = 0;
-    int rc = msspe_cross_dimer_edges(eng.ctx(), flat.data(), n, k, &chem, opts.dg, edges.data(), edges.size(), &count);
+    // (with --devices: the rows of the pair matrix dealt out over the group, the same edges in the same order)
+    auto screen = [&]() {
+        return eng.group() ? msspe_cross_dimer_edges_group(eng.group(), flat.data(), n, k, &chem, opts.dg, edges.data(),
+                                                           edges.size(), &count)
+                           : msspe_cross_dimer_edges(eng.ctx(), flat.data(), n, k, &chem, opts.dg, edges.data(), edges.size(),
+                                                     &count);
+    };
+    int rc = screen();
     if (rc == MSSPE_ERR_CAPACITY) {
         edges.resize((size_t)count);
-        rc = msspe_cross_dimer_edges(eng.ctx(), flat.data(), n, k, &chem, opts.dg, edges.data(), edges.size(), &count);
+        rc = screen();
     }
-    if (rc) eng.fail(rc);
+    if (rc) eng.group() ? eng.fail_group(rc) : eng.fail(rc);
     for (uint64_t e = 0; e < count; ++e) {
         const std::string &a = g.nodes[edges[(size_t)e].a], &b = g.nodes[edges[(size_t)e].b];
         // delta_g.rs:66-69: pairs never sent to ntthal when self-dimer checking is off
@@ -754,7 +788,20 @@ int run(const Args &args, std::string &stdout_text)
                          args.max_self_dimer_end_tm, args.max_hairpin_tm};
     cfg.stddev_population = args.stddev_population;
 
-    Engine eng(args.device, args.params_path);
+    std::vector<int> devices;   // --devices 0,1,...: a group; otherwise the one context of --device
+    for (size_t at = 0; at < args.devices.size();) {
+        size_t comma = args.devices.find(',', at);
+        if (comma == std::string::npos) comma = args.devices.size();
+        const std::string tok = args.devices.substr(at, comma - at);
+        char *end = nullptr;
+        const long d = std::strtol(tok.c_str(), &end, 10);
+        if (tok.empty() || *end || d < 0) throw UsageError("error: invalid value '" + args.devices + "' for '--devices'");
+        devices.push_back((int)d);
+        at = comma + 1;
+    }
+    std::unique_ptr<Engine> eng_owner(devices.empty() ? new Engine(args.device, args.params_path)
+                                                      : new Engine(devices, args.params_path));
+    Engine &eng = *eng_owner;
     const DeviceAlignment aln(eng, records);   // one upload for stage A (both directions) and the report
     timer.lap("engine + alignment upload");
     const auto cand_f = find_candidates_kmers(eng, aln, SEQ_DIR_FWD, cfg, args.window_size,

@@ -50,6 +50,7 @@ struct Args {
     std::string ntthal = "ntthal", primer3 = "primer3_core";   // accepted for compatibility, unused
     // engine-only switches (not in the reference)
     int device = 0;
+    std::string devices;           // "0,1,2,...": the N^2 pair loop and stage B run on a group of devices (msspe_group_*)
     std::string params_path;       // Primer3 config directory; empty = bundled tables
     bool stddev_population = false;  // crate std-dev 0.1.0's divisor is unpinned
     static Args parse(int argc, const char *const *argv);   // throws UsageError
@@ -110,17 +111,21 @@ struct ConflictGraph {
     std::map<std::string, std::set<std::string>> edges;   // directed: a -> {b : dG(a,b) < threshold}
 };
 
-class Engine {   // owns one msspe_ctx
+class Engine {   // owns one msspe_ctx, or a group of them (one per device of --devices)
 public:
     Engine(int device, const std::string &params_path);
+    Engine(const std::vector<int> &devices, const std::string &params_path);
     ~Engine();
     Engine(const Engine &) = delete;
     Engine &operator=(const Engine &) = delete;
-    msspe_ctx *ctx() const { return ctx_; }
+    msspe_ctx *ctx() const { return ctx_; }         // with a group: member 0 (stage A, the coverage report)
+    msspe_group *group() const { return group_; }   // nullptr: one device
     [[noreturn]] void fail(int rc) const;
+    [[noreturn]] void fail_group(int rc) const;
 
 private:
     msspe_ctx *ctx_ = nullptr;
+    msspe_group *group_ = nullptr;
 };
 
 // The alignment as the device sees it: one rectangular byte matrix (rows shorter than the longest

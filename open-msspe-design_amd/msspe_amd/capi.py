@@ -24,6 +24,9 @@ EXPORTS = [
     "msspe_packed_row_words", "msspe_device_put_rows_packed", "msspe_kmer_candidates_packed_dev",
     "msspe_segment_coverage_packed_dev",
     "msspe_round_fixed_f32", "msspe_g_cut",
+    "msspe_group_create", "msspe_group_destroy", "msspe_group_last_error", "msspe_group_size",
+    "msspe_group_transport", "msspe_group_member", "msspe_group_set_option", "msspe_group_rows",
+    "msspe_cross_dimer_group", "msspe_cross_dimer_edges_group", "msspe_oligo_stats_group",
 ]
 
 
@@ -93,6 +96,22 @@ def load_library() -> C.CDLL:
     L.msspe_set_stream.argtypes = [vp, vp]
     L.msspe_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.msspe_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
+    L.msspe_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.msspe_group_destroy.argtypes = [vp]
+    L.msspe_group_destroy.restype = None
+    L.msspe_group_last_error.argtypes = [vp]
+    L.msspe_group_last_error.restype = C.c_char_p
+    L.msspe_group_size.argtypes = [vp]
+    L.msspe_group_transport.argtypes = [vp]
+    L.msspe_group_transport.restype = C.c_char_p
+    L.msspe_group_member.argtypes = [vp, C.c_int]
+    L.msspe_group_member.restype = vp
+    L.msspe_group_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.msspe_group_rows.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.msspe_cross_dimer_group.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float, vp, vp]
+    L.msspe_cross_dimer_edges_group.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem), C.c_float, vp,
+                                                C.c_uint64, C.POINTER(C.c_uint64)]
+    L.msspe_oligo_stats_group.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(Chem)] + [vp] * 5
     L.msspe_reset_stream.argtypes = [vp]
     L.msspe_synchronize.argtypes = [vp]
     L.msspe_pack_oligos.argtypes = [C.c_char_p, C.c_int, C.c_int, u64p]
@@ -366,3 +385,91 @@ class Engine:
                 words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
         m = n_out.value
         return [unpack_oligo(w, opt.kmer_size) for w in words[:m]], freqs[:m].copy()
+
+
+def group_rows(n: int, n_members: int, member: int) -> np.ndarray:
+    """Pool rows a member of a group screens (include/msspe_hip.h msspe_group_rows; host only)."""
+    L = load_library()
+    cnt = C.c_int(0)
+    rc = L.msspe_group_rows(n, n_members, member, None, 0, C.byref(cnt))
+    if rc:
+        raise MsspeError(rc, "msspe_group_rows: bad argument")
+    rows = np.zeros(max(cnt.value, 1), dtype=np.uint32)
+    rc = L.msspe_group_rows(n, n_members, member, rows.ctypes.data, int(rows.size), C.byref(cnt))
+    if rc:
+        raise MsspeError(rc, "msspe_group_rows failed")
+    return rows[:cnt.value]
+
+
+class Group:
+    """Several devices of one node in one process (include/msspe_hip.h msspe_group_*): one context per listed
+    device; a device listed more than once = members sharing a card (the rehearsal mode, transport device-copy)."""
+
+    def __init__(self, devices, params_path: str | None = None, transport: str | None = None):
+        self.L = load_library()
+        self.ptr = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self.L.msspe_group_create(arr, len(devices), params_path.encode() if params_path else None,
+                                       transport.encode() if transport else None, C.byref(self.ptr))
+        if rc:
+            msg = self.L.msspe_group_last_error(self.ptr).decode() if self.ptr else "allocation failed"
+            if self.ptr:
+                self.L.msspe_group_destroy(self.ptr)
+                self.ptr = C.c_void_p()
+            raise MsspeError(rc, msg)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.L.msspe_group_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise MsspeError(rc, self.L.msspe_group_last_error(self.ptr).decode())
+
+    @property
+    def size(self) -> int:
+        return int(self.L.msspe_group_size(self.ptr))
+
+    @property
+    def transport(self) -> str:
+        return self.L.msspe_group_transport(self.ptr).decode()
+
+    def set_option(self, key: str, value) -> None:
+        self._check(self.L.msspe_group_set_option(self.ptr, key.encode(), str(value).encode()))
+
+    def cross_dimer(self, pool, chem: Chem | None = None, threshold: float = -9000.0, want_bitmap=True):
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.ntthal()
+        rc_ = np.zeros(n, dtype=np.uint32)
+        bm = np.zeros((n, (n + 63) // 64), dtype=np.uint64) if want_bitmap else None
+        self._check(self.L.msspe_cross_dimer_group(self.ptr, buf, n, k, C.byref(chem), C.c_float(threshold),
+                                                   rc_.ctypes.data, bm.ctypes.data if want_bitmap else None))
+        return {"row_conflicts": rc_, "bitmap": bm}
+
+    def cross_dimer_edges(self, pool, chem: Chem | None = None, threshold: float = -9000.0, capacity: int = 1 << 20):
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.ntthal()
+        edges = np.zeros(capacity, dtype=np.dtype([("a", np.uint32), ("b", np.uint32), ("dg", np.float32)]))
+        count = C.c_uint64()
+        rc = self.L.msspe_cross_dimer_edges_group(self.ptr, buf, n, k, C.byref(chem), C.c_float(threshold),
+                                                  edges.ctypes.data, capacity, C.byref(count))
+        if rc:
+            err = MsspeError(rc, self.L.msspe_group_last_error(self.ptr).decode())
+            err.count = int(count.value)
+            raise err
+        return edges[:count.value], int(count.value)
+
+    def oligo_stats(self, pool, chem: Chem | None = None):
+        buf, n, k = _ascii(pool)
+        chem = chem or Chem.primer3()
+        out = {name: np.empty(n) for name in ("tm", "gc", "self_any", "self_end", "hairpin")}
+        self._check(self.L.msspe_oligo_stats_group(self.ptr, buf, n, k, C.byref(chem),
+                                                   *[out[x].ctypes.data for x in out]))
+        return out
