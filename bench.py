@@ -135,35 +135,45 @@ def cpu_baseline(pool_ascii: np.ndarray, seconds: float, gpu_bitmap_rows: np.nda
 
 def stage_a_line(eng, device):
     """Stage A (k-mer candidates, the HBM-bound part of the path) on BASELINE.json configs[2]'s shape:
-    10,000 synthetic aligned genomes of 30 kb, both directions, alignment resident in HBM.  Algorithmic
-    bytes per direction: 100 B of window per segment read, 38 instances x 12 B written and
-    sorted once, 38 x 4 B of count updates when the segment is covered."""
+    10,000 synthetic aligned genomes of 30 kb, both directions, the alignment resident in HBM in its packed
+    form (2-bit bases + validity bit: what msspe_device_put_rows_packed leaves there).  Algorithmic bytes per
+    direction: the windows' packed bits read (50 columns x 3 bits per segment), 38 keys x 4 B
+    written, sorted with their 4-byte instance numbers and indexed once (post + word ids: 38 x 8 B), 38 x 4 B
+    of count updates when the segment is covered."""
     n_rows, length = 10000, 30000
     genomes = msspe_amd.synth.aligned_genomes(n_rows, length)
-    d = torch.from_numpy(genomes).to(device)
+    d = eng.put_rows_packed(genomes)
     opt = msspe_amd.KmerOpt(500, 250, 50, K, 1000, 10)
     out = {}
-    for direction in (0, 1):
-        eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=n_rows, seq_len=length)
-    torch.cuda.synchronize()
-    reps = 3
-    t0 = time.perf_counter()
-    winners = 0
-    for _ in range(reps):
+    try:
         for direction in (0, 1):
-            w, _f = eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=n_rows, seq_len=length)
-            winners += len(w)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / (2 * reps) * 1e3
+            eng.kmer_candidates_packed(d, n_rows, length, opt, direction)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        winners = 0
+        its = np.zeros(4)
+        for _ in range(reps):
+            for direction in (0, 1):
+                w, _f = eng.kmer_candidates_packed(d, n_rows, length, opt, direction)
+                winners += len(w)
+                its += [eng.info("stage_a_" + x) for x in ("fast_iterations", "general_iterations", "rebuilds", "idle_iterations")]
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (2 * reps) * 1e3
+    finally:
+        eng.device_free(d)
     segments = n_rows * ((length - 500) // 250 + 1)
-    alg_bytes = segments * (100.0 + 38 * 12.0 + 38 * 4.0)
-    out.update({"workload": f"{n_rows} synthetic aligned genomes x {length} columns, k = {K}, both directions",
+    alg_bytes = segments * (19.0 + 38 * 4.0 + 38 * 8.0 + 38 * 8.0 + 38 * 4.0)
+    its /= 2 * reps
+    out.update({"workload": f"{n_rows} synthetic aligned genomes x {length} columns (packed), k = {K}, both directions",
                 "ms_per_direction": ms, "winners_per_direction": winners / (2 * reps),
+                "greedy_iterations_per_direction": {"from_partition_leaders": its[0], "after_posting_walks": its[1],
+                                                    "candidate_lists_made": its[2]},
                 "algorithmic_bytes_per_direction": alg_bytes,
                 "GBps": alg_bytes / (ms * 1e-3) / 1e9,
                 "frac_of_6.29TBps_copy_ceiling": alg_bytes / (ms * 1e-3) / 6.29e12,
-                "note": "host wall time per direction incl. the greedy loop's dependent launches (launch-latency "
-                        "bound, not bandwidth bound: see DESIGN.md 4.3)"})
+                "note": "host wall time per direction incl. the greedy loop's dependent launches and its host "
+                        "round trips; per-kernel times: profiles/r03_stage_a_kernel_stats.csv, DESIGN.md 4.3"})
     return out
 
 

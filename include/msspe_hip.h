@@ -95,7 +95,11 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value);
  *   "device"          HIP ordinal           "n_cu"  compute units
  *   "lds_reads_zero"  1: the per-engine probe found that LDS reads beyond a block's allocation return 0 (every
  *                     gfx950 seen), i.e. the row-specialised first stage may run; 0: the general kernel runs
- *   "row_kernel"      1: 13-mer pools go to the row-specialised first stage with the current options */
+ *   "row_kernel"      1: 13-mer pools go to the row-specialised first stage with the current options
+ *   "stage_a_fast_iterations" / "stage_a_general_iterations" / "stage_a_rebuilds" / "stage_a_idle_iterations"
+ *                     the last msspe_kmer_candidates* call's greedy loop: iterations that recorded winners from the
+ *                     partitions' leaders alone / after a walk over posting lists, candidate lists made, idle
+ *                     iterations at the end of the last batch */
 int msspe_get_info(msspe_ctx *ctx, const char *key, long long *value_out);
 int msspe_set_stream(msspe_ctx *ctx, void *hip_stream);
 int msspe_reset_stream(msspe_ctx *ctx);
@@ -282,6 +286,11 @@ int msspe_device_put_rows(msspe_ctx *ctx, const char *const *rows, const size_t 
  * main.rs:167).  msspe_device_put_rows_packed uploads the rows 16 MB at a time and packs each chunk on the
  * device; the *_packed_dev entry points are msspe_kmer_candidates_dev / msspe_segment_coverage_dev on that form
  * (same outputs; 3/8 of the bytes resident and read). */
+/* Diagnostics of the last msspe_kmer_candidates* call (engine-only): per winner, iteration << 8 | how the greedy
+ * loop selected it -- 1 a partition's leader read off the counts, 2 a word with postings in several partitions,
+ * 3 such a word after its key was re-computed, 4 after a walk over posting lists, 0 the all-words loop.
+ * *n_out = number of winners (also when capacity is smaller). */
+int msspe_kmer_trace(msspe_ctx *ctx, uint32_t *out, int capacity, int *n_out);
 size_t msspe_packed_row_words(size_t seq_len);
 int msspe_device_put_rows_packed(msspe_ctx *ctx, const char *const *rows, const size_t *row_bytes, int n_rows,
                                  size_t row_len, void **device_out);

@@ -399,7 +399,20 @@ int msspe_get_info(msspe_ctx *ctx, const char *key, long long *value_out)
     else if (k == "lds_reads_zero") *value_out = ctx->lds_reads_zero ? 1 : 0;
     else if (k == "row_kernel")
         *value_out = ctx->lds_reads_zero && ctx->opt.row_oob && ctx->opt.pair_kernel == 0 && !ctx->opt.force_generic ? 1 : 0;
+    else if (k == "stage_a_fast_iterations") *value_out = ctx->kmer.loop_stats()[0];
+    else if (k == "stage_a_general_iterations") *value_out = ctx->kmer.loop_stats()[1];
+    else if (k == "stage_a_rebuilds") *value_out = ctx->kmer.loop_stats()[2];
+    else if (k == "stage_a_idle_iterations") *value_out = ctx->kmer.loop_stats()[3];
     else return fail(ctx, MSSPE_ERR_ARG, "msspe_get_info: unknown key '" + k + "'");
+    return MSSPE_OK;
+}
+
+int msspe_kmer_trace(msspe_ctx *ctx, uint32_t *out, int capacity, int *n_out)
+{
+    if (!ctx || !n_out || capacity < 0 || (capacity && !out)) return MSSPE_ERR_ARG;
+    const auto &t = ctx->kmer.trace();
+    *n_out = (int)t.size();
+    for (int i = 0; i < capacity && i < (int)t.size(); ++i) out[i] = t[(size_t)i];
     return MSSPE_OK;
 }
 

@@ -26,6 +26,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/functional.hpp>
 
 namespace msspe {
@@ -46,16 +47,20 @@ struct Status {
     unsigned n_long;   // tied words with a long posting list (kept at the back of `tied`)
     unsigned ticket;   // last-block detection
     unsigned long long best;   // winner_key() maximum over the tied words
-    // candidate-list loop (k_select / k_cover<true>): every word whose live count is >= theta is in cand[]
+    // candidate-list loop (k_score / k_prefix / k_cover_multi): every word whose live count is >= theta is in cand[]
     int theta;
     unsigned n_cand;
-    int need_rebuild;  // 1: the candidates' maximum fell below theta; the rest of the batch is a no-op
-    unsigned it1;      // stamp of the iteration in flight (n_win + 1)
+    int need_rebuild;  // 1: a new candidate list is wanted (the iteration's remaining kernels are no-ops); 2: rebuilt in this iteration
     int last_max;      // the maximum the last k_max_count saw (the host's capacity check)
-    int too_many;      // 1: the candidate list is longer than k_select reads; the host runs a five-launch batch
-    unsigned long long best2[2];   // `best` of the candidate-list loop, alternating with the iteration
+    int too_many;      // 1: the candidate list is longer than k_score reads, or too many words tie: the host runs five-launch batches
+    // statistics of the candidate-list loop: iterations that recorded winners through k_fast / through k_score + k_prefix,
+    // iterations that rebuilt the list, and iterations that found the loop over or waiting for a rebuild
+    int it_fast, it_general, it_rebuild, it_idle;
+    unsigned n_mcand;  // candidates with postings in several partitions (the list behind cand[])
+    unsigned epoch;    // number of the candidate list (cand_flag[word] == epoch: the word is on it)
+    int want_general;  // k_fast could not settle the iteration: the host runs k_score / k_prefix / k_cover_multi once
 };
-static_assert(sizeof(Status) <= 128, "the winners' arrays start 128 bytes into the status buffer");
+static_assert(sizeof(Status) <= 256, "the winners' arrays start 256 bytes into the status buffer");
 
 // Segment ids are genome-major (seg = genome * P + partition: the order the reference walks
 // them in), but a winner's postings are mostly one partition of many genomes.  The per-segment
@@ -106,58 +111,85 @@ __global__ void __launch_bounds__(256) k_pack_rows(const uint8_t *ascii, int n_r
     packed[t] = out;
 }
 
-// One thread per (segment, window position).  key = lexicographic-order code of the emitted word
-// (first base in the most significant bits); invalid / duplicate positions get the sentinel.
-// Key = uint32_t when the 2k + 1 key bits fit (k <= 15: a third less sort traffic), uint64_t otherwise.
+// Extraction (main.rs:163-235): one wave per search window, lane = window position, from the PACKED alignment.
+// A window's 2-bit bases are a run of bits in two or three 64-bit words of its row, which all the lanes of the wave
+// read (one broadcast load each); lane p cuts its k bases out with two shifts -- x, base q of the k-mer in bits
+// [2q, 2q+1] -- and its k validity bits the same way.  The emitted key is the word's lexicographic code (first
+// base in the most significant bits): for the head window the 2-bit groups of x reversed (bit reverse + swap
+// within pairs), for the tail window, whose k-mers are stored reverse-complemented (main.rs:213-224), simply the
+// complement of x -- reversing the order and reading LSB-first instead of MSB-first cancel.  First occurrence per
+// window (itertools::unique, main.rs:168): the wave's valid lanes enter their x into a small open-addressing table
+// in LDS (compare-and-swap on the key, minimum on the position) and keep their word iff they hold the minimum.
+// Only the keys are written, 4 (k <= 15) or 8 bytes per window position in one contiguous run per wave; the
+// instance numbers the sort carries along come from a counting iterator.
+constexpr int kExtTab = 512;   // table slots per wave (a window has at most 256 positions: KmerStage::run)
+
 template <class Key>
-__global__ void __launch_bounds__(256) k_extract(const SeqView seqs, size_t seq_len, int n_seg,
-                                                 int P, int seg_size, int stride, int W, int k,
-                                                 int direction, int per, int wins_per_block,
-                                                 Key *key_out, uint32_t *val_out)
+__global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t seq_len, int n_seg, int P, int seg_size,
+                                                 int stride, int W, int k, int direction, int per, Key *key_out)
 {
-    extern __shared__ unsigned char smem[];
-    uint64_t *fkey = (uint64_t *)smem;                           // [wins_per_block][per] forward keys
-    uint8_t *win = smem + sizeof(uint64_t) * wins_per_block * per;   // [wins_per_block][W]
-    const int t = threadIdx.x;
-    const int w = t / per, p = t % per;
-    const long seg0 = (long)blockIdx.x * wins_per_block;
-    // stage the windows
-    for (int e = t; e < wins_per_block * W; e += blockDim.x) {
-        const long seg = seg0 + e / W;
-        uint8_t c = 'N';
-        if (seg < n_seg) {
-            const long rec = seg / P, part = seg % P;
-            const size_t col = (size_t)part * stride + (direction ? seg_size - W : 0) + (e % W);
-            c = seq_at(seqs, (size_t)rec, col);
-        }
-        win[e] = c;
+    __shared__ unsigned long long tab_x[4][kExtTab];
+    __shared__ int tab_p[4][kExtTab];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+    const size_t bw = (seq_len + 31) / 32, vw = (seq_len + 63) / 64, rw = bw + vw;
+    const unsigned long long xmask = (1ull << (2 * k)) - 1ull, vmask = (1ull << k) - 1ull;
+    const Key sentinel = (Key)(1ull << (2 * k));
+    for (int e = lane; e < kExtTab; e += 64) {
+        tab_x[wv][e] = ~0ull;
+        tab_p[wv][e] = 0x7fffffff;
     }
-    __syncthreads();
-    const long seg = seg0 + w;
-    const bool mine = w < wins_per_block && seg < n_seg;
-    uint64_t fk = ~0ull, word = 0;
-    if (mine) {
-        bool ok = true;
-        uint64_t f = 0, rc = 0;
-        for (int q = 0; q < k; ++q) {
-            const int b = base2(win[w * W + p + q]);
-            ok = ok && b >= 0;
-            f = (f << 2) | (uint64_t)(b & 3);                      // forward word, MSB first
-            rc |= (uint64_t)(3 - (b & 3)) << (2 * q);              // reverse complement, MSB first
+    __builtin_amdgcn_wave_barrier();
+    for (int seg = wave; seg < n_seg; seg += n_waves) {   // wave-uniform
+        int hs[4] = {-1, -1, -1, -1};   // the lane's table slots of this window (one per pass of 64 positions)
+        const int rec = seg / P, part = seg - rec * P;
+        const uint64_t *row = packed + (size_t)rec * rw;
+        const size_t c0 = (size_t)part * (size_t)stride + (size_t)(direction ? seg_size - W : 0);
+        for (int p0 = 0; p0 < per; p0 += 64) {   // (windows wider than 64 + k - 1 take several passes; dedup spans them)
+            const int p = p0 + lane;
+            const bool in = p < per;
+            const size_t col = c0 + (size_t)(in ? p : 0);
+            const size_t w0 = col >> 5, v0 = col >> 6;
+            const int sh = (int)(col & 31) * 2, vs = (int)(col & 63);
+            const unsigned long long lo = row[w0], hi = w0 + 1 < bw ? row[w0 + 1] : 0ull;
+            const unsigned long long vlo = row[bw + v0], vhi = v0 + 1 < vw ? row[bw + v0 + 1] : 0ull;
+            const unsigned long long x = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & xmask;
+            const unsigned long long vb = ((vlo >> vs) | (vs ? vhi << (64 - vs) : 0ull)) & vmask;
+            const bool ok = in && vb == vmask;
+            // first occurrence in the window
+            int h = 0;
+            if (ok) {
+                h = (int)((x * 0x9e3779b97f4a7c15ull) >> 55);   // 9 bits
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&tab_x[wv][h], ~0ull, x);
+                    if (old == ~0ull || old == x) break;
+                    h = (h + 1) & (kExtTab - 1);
+                }
+                atomicMin(&tab_p[wv][h], p);
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool keep = false;
+            if (ok) keep = tab_p[wv][h] == p;
+            unsigned long long word;
+            if (direction) {
+                word = ~x & xmask;
+            } else {
+                unsigned long long r = __brevll(x) >> (64 - 2 * k);
+                word = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+            }
+            if (in) key_out[(size_t)seg * per + p] = keep ? (Key)word : sentinel;
+            hs[p0 >> 6] = ok ? h : -1;
         }
-        if (ok) {
-            fk = f;
-            word = direction ? rc : f;
-        }
-        fkey[w * per + p] = fk;
+        __builtin_amdgcn_wave_barrier();
+        // the table is the next window's: every entry that was used goes back to empty
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 64 < per && hs[q] >= 0) {
+                tab_x[wv][hs[q]] = ~0ull;
+                tab_p[wv][hs[q]] = 0x7fffffff;
+            }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (!mine) return;
-    bool keep = fk != ~0ull;
-    for (int q = 0; keep && q < p; ++q) keep = fkey[w * per + q] != fk;   // first occurrence only
-    const size_t inst = (size_t)seg * per + p;
-    key_out[inst] = (Key)(keep ? word : (1ull << (2 * k)));
-    val_out[inst] = (uint32_t)inst;
 }
 
 template <class Key>
@@ -172,7 +204,8 @@ __global__ void k_heads(const Key *key, size_t n, uint64_t sentinel, uint32_t *h
 template <class Key>
 __global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *head,
                         const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G,
-                        int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys)
+                        int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys,
+                        uint16_t *word_part, uint8_t *word_multi)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -190,6 +223,9 @@ __global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *hea
     if (head[i]) {
         post_off[kid] = (uint32_t)i;
         ukeys[kid] = k;
+        word_part[kid] = (uint16_t)(seg % (uint32_t)P);   // the partition of the word's first posting ...
+    } else if ((val[i - 1] / (uint32_t)per) % (uint32_t)P != seg % (uint32_t)P) {
+        word_multi[kid] = 1;   // ... and whether any two neighbouring postings differ in theirs (cleared by the host)
     }
 }
 
@@ -220,11 +256,19 @@ __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
 constexpr unsigned kLongList = 512;
 constexpr int kTieUnroll = 4;        // 1024-posting chunks whose loads k_tie_long keeps in flight   // posting lists above this get a whole block in k_tie_long
 
+// kRebuild: head of the candidate-list loop's iteration.  It runs only when a new list was asked for
+// (st->need_rebuild == 1, or `force`); its last block turns the request into "rebuilt in this iteration" (2), which
+// k_collect_cand waits for and k_prefix takes back to 0.  (The flags are written by the last block only, i.e.
+// after every block has passed this test: no block can see them change under it.)
 template <bool kRebuild>
-__global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st)
+__global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, Status *st, int force, int32_t *live_part,
+                                                   int P)
 {
     __shared__ int part[4];
+    __shared__ int last_sh;
+    if (threadIdx.x == 0) last_sh = 0;
     if (st->stop) return;
+    if (kRebuild && !force && st->need_rebuild == 0) return;
     int m = 0;
     {
         // 16-byte loads (the count array is 256-byte aligned), the last M % 4 words one by one
@@ -254,16 +298,23 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
                 // below theta the winner and everything tied with it are among the words collected now
                 st->theta = max(2, mf / 2);
                 st->n_cand = 0;
-                st->need_rebuild = 0;
+                st->n_mcand = 0;
+                st->epoch += 1;
+                last_sh = 1;
+                st->need_rebuild = 2;
                 st->too_many = 0;
                 st->maxf = 0;
-                st->best2[0] = 0;
-                st->best2[1] = 0;
             }
             st->n_tied = 0;
             st->n_long = 0;
             st->ticket = 0;
         }
+    }
+    if (kRebuild) {
+        // a new list: live_part[p] is counted afresh by k_mark (segments of p that hold a word of the list)
+        __syncthreads();
+        if (last_sh && live_part)
+            for (int p = threadIdx.x; p < P; p += 256) live_part[p] = 0;
     }
 }
 
@@ -297,10 +348,15 @@ __global__ void __launch_bounds__(256) k_collect_tied(const int32_t *count, int 
 // posting list (the class k_tie_long / tie_score_block serves).
 constexpr uint32_t kCandLong = 0x80000000u;
 
+// mcand: the candidates with postings in several partitions, once more (k_multi walks those; at most kMaxMulti are
+// stored, the count goes on)
+constexpr unsigned kMaxMulti = 512;
+
 __global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int M, Status *st,
-                                                      const uint32_t *post_off, uint32_t *cand)
+                                                      const uint32_t *post_off, uint32_t *cand,
+                                                      const uint8_t *word_multi, uint32_t *mcand, uint32_t *cand_flag)
 {
-    if (st->stop) return;
+    if (st->stop || st->need_rebuild != 2) return;   // only behind a k_max_count<true> that rebuilt
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool hit = i < M && count[i] >= st->theta;
@@ -313,7 +369,50 @@ __global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int 
         if (hit)
             cand[base + (unsigned)__popcll(mh & ((1ull << lane) - 1ull))] =
                 (uint32_t)i | (post_off[i + 1] - post_off[i] > kLongList ? kCandLong : 0u);
+        if (hit) cand_flag[i] = st->epoch;
+        if (hit && word_multi[i]) {   // rare: one atomic each
+            const unsigned at = atomicAdd(&st->n_mcand, 1u);
+            if (at < kMaxMulti) mcand[at] = (uint32_t)i;
+        }
     }
+}
+
+// Behind a new candidate list: which live segments hold a word of the list (marked), and how many of them each
+// partition has (live_part).  A word of the list can only lose marked segments, and after a cover of f live segments
+// of partition p every word living in p has at most live_part[p] - f left: k_fast's bound.  (Segments that hold rare
+// words only -- most of what is left late in the loop -- do not count.)  One wave per segment, lane = window position;
+// rows are partition-major, so a wave's consecutive rows share a partition and one atomic serves many.
+__global__ void __launch_bounds__(256) k_mark(const Status *st, const int32_t *kid_of_inst, const uint8_t *ignored,
+                                              const uint32_t *cand_flag, int n_seg, int per, int G, uint8_t *marked,
+                                              int32_t *live_part)
+{
+    if (st->stop || st->need_rebuild != 2) return;
+    const uint32_t epoch = st->epoch;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int rows_per = (n_seg + n_waves - 1) / n_waves;   // a contiguous run of rows per wave
+    const int r0 = wave * rows_per, r1 = min(n_seg, r0 + rows_per);
+    int acc = 0, acc_part = -1;
+    for (int row = r0; row < r1; ++row) {
+        bool any = false;
+        if (!ignored[row]) {
+            for (int q0 = 0; q0 < per; q0 += 64) {
+                const int q = q0 + lane;
+                const int32_t kid = q < per ? kid_of_inst[(size_t)row * per + q] : -1;
+                any = any || (kid >= 0 && cand_flag[kid] == epoch);
+            }
+            any = __ballot(any) != 0ull;
+        }
+        if (lane == 0) marked[row] = any ? 1 : 0;
+        const int part = row / G;
+        if (part != acc_part) {
+            if (acc && lane == 0) atomicAdd(&live_part[acc_part], acc);
+            acc = 0;
+            acc_part = part;
+        }
+        acc += any ? 1 : 0;
+    }
+    if (acc && lane == 0) atomicAdd(&live_part[acc_part], acc);
 }
 
 // winner = highest score, then smallest word (= smallest id: ids follow the sorted key order).
@@ -327,12 +426,17 @@ __device__ __forceinline__ unsigned long long winner_key(float score, uint32_t k
 // covered segments, and on the first sight of each partition add 1 / (coverage + 1) in f32 (the
 // order of the additions is the reference's).  One wave per tied word; `seen` is a per-wave bitmap
 // in LDS.
-__device__ __forceinline__ float tie_score_wave(uint32_t kid, unsigned *seen, int words, int lane,
+// allp (optional): a second bitmap that receives the partitions of ALL the postings, covered segments included
+// (what main.rs:371-378 bumps the coverage of when the word wins).
+__device__ __forceinline__ float tie_score_wave(uint32_t kid, unsigned *seen, unsigned *allp, int words, int lane,
                                                 const uint32_t *post_off, const uint32_t *post,
                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G)
 {
     constexpr int kDeep = 8;   // 64-posting chunks whose (post -> ignored) loads are in flight together
-    for (int wd = lane; wd < words; wd += 64) seen[wd] = 0u;
+    for (int wd = lane; wd < words; wd += 64) {
+        seen[wd] = 0u;
+        if (allp) allp[wd] = 0u;
+    }
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     float acc = 0.0f;
     for (uint32_t base = b; base < e; base += 64 * kDeep) {
@@ -348,8 +452,19 @@ __device__ __forceinline__ float tie_score_wave(uint32_t kid, unsigned *seen, in
             live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
 #pragma unroll
         for (int u = 0; u < kDeep; ++u) {
-            const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int pall = seg[u] != 0xffffffffu ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int part = live[u] ? pall : -1;
             const int ps = live[u] ? part : 0;
+            if (allp) {   // wave-uniform
+                const int pq = pall >= 0 ? pall : 0;
+                unsigned long long ma = __ballot(pall >= 0 && !((allp[pq >> 5] >> (pq & 31)) & 1u));
+                while (ma) {
+                    const int l = __ffsll((long long)ma) - 1;
+                    const int pl = __shfl(pall, l);
+                    ma &= ~__ballot(pall == pl);
+                    if (lane == 0) allp[pl >> 5] |= 1u << (pl & 31);
+                }
+            }
             unsigned long long m = __ballot(live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u));
             while (m) {   // wave-uniform: distinct new partitions in ascending posting order
                 const int l = __ffsll((long long)m) - 1;
@@ -381,7 +496,7 @@ __global__ void __launch_bounds__(256) k_tie_scores(const uint32_t *tied, Status
     unsigned long long best = 0;
     for (unsigned tix = blockIdx.x * 4 + wave; tix < n; tix += gridDim.x * 4) {
         const uint32_t kid = tied[tix];
-        const float acc = tie_score_wave(kid, seen, words, lane, post_off, post, ignored, coverage, P, G);
+        const float acc = tie_score_wave(kid, seen, nullptr, words, lane, post_off, post, ignored, coverage, P, G);
         const unsigned long long key = winner_key(acc, kid);
         best = key > best ? key : best;
     }
@@ -400,13 +515,16 @@ struct TieBlockShared {
     int part;       // the partition being taken
 };
 
-__device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, TieBlockShared *sh, int words,
+__device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, unsigned *allp, TieBlockShared *sh, int words,
                                                 const uint32_t *post_off, const uint32_t *post,
                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G)
 {
     constexpr int kExtract = 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int wd = threadIdx.x; wd < words; wd += 1024) seen[wd] = 0u;
+    for (int wd = threadIdx.x; wd < words; wd += 1024) {
+        seen[wd] = 0u;
+        if (allp) allp[wd] = 0u;   // allp (optional): the partitions of ALL the postings, see tie_score_wave
+    }
     if (threadIdx.x == 0) {
         sh->acc = 0.0f;
         sh->first[0] = 0x7fffffff;
@@ -430,8 +548,19 @@ __device__ __forceinline__ void tie_score_block(uint32_t kid, unsigned *seen, Ti
             live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
 #pragma unroll
         for (int u = 0; u < kTieUnroll; ++u) {
-            const int part = live[u] ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int pall = seg[u] != 0xffffffffu ? (int)(seg[u] % (uint32_t)P) : -1;
+            const int part = live[u] ? pall : -1;
             const int ps = live[u] ? part : 0;   // in-bounds bitmap index for idle lanes
+            if (allp) {   // block-uniform; a wave merges its lanes, the waves' bits meet in an LDS atomic
+                const int pq = pall >= 0 ? pall : 0;
+                unsigned long long ma = __ballot(pall >= 0 && !((allp[pq >> 5] >> (pq & 31)) & 1u));
+                while (ma) {
+                    const int l = __ffsll((long long)ma) - 1;
+                    const int pl = __shfl(pall, l);
+                    ma &= ~__ballot(pall == pl);
+                    if (lane == 0) atomicOr(&allp[pl >> 5], 1u << (pl & 31));
+                }
+            }
             bool fresh = live[u] && !((seen[ps >> 5] >> (ps & 31)) & 1u);
             bool more = true;
             for (int round = 0; round < kExtract; ++round) {
@@ -498,55 +627,641 @@ __global__ void __launch_bounds__(1024) k_tie_long(const uint32_t *tied, int M, 
     }
     for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
         const uint32_t kid = tied[(unsigned)M - 1u - j];
-        tie_score_block(kid, seen, &tb, words, post_off, post, ignored, coverage, P, G);
+        tie_score_block(kid, seen, nullptr, &tb, words, post_off, post, ignored, coverage, P, G);
         if (threadIdx.x == 0) atomicMax(&st->best, winner_key(tb.acc, kid));
         __syncthreads();
     }
 }
 
-// ---- candidate-list loop -------------------------------------------------------------------------------
-// One iteration = k_select -> k_cover<true>.  A batch starts with k_max_count<true> + k_collect_cand, which
-// gather the words whose live count is at least theta = max / 2 (a few thousand, against millions of words).
-// Counts only fall, so while the candidates' maximum stays >= theta it is the global maximum and every word
-// tied with it is a candidate: k_select finds the maximum and the tied words by reading the candidates only,
-// every block for itself (no grid-wide step), scores its share of them and posts winner_key() maxima.
-// When the maximum falls below theta the rest of the batch is a no-op and the next batch starts from a
-// fresh list.  The decisions are those of the five-launch iteration: same maximum, same tied set, same
-// scores, same winner.
+// ---- candidate-list loop: several winners per iteration ---------------------------------------------------
+// A batch of iterations starts with k_max_count<true> + k_collect_cand, which gather the words whose live count
+// is at least theta = max / 2 (a few thousand, against millions of words).  Counts only fall, so while the
+// candidates' maximum stays >= theta it is the global maximum and every word near it is a candidate.
+//
+// One iteration = k_score -> k_prefix -> k_cover_multi and selects a whole PREFIX of the greedy order, exactly:
+// let w1, w2, ... be the words in the loop's order (count desc, partition_tie_score desc, word asc) right now.
+// Covering w1 (main.rs:371-378) only LOWERS other words' keys -- it takes live segments away (count, score) and
+// raises the coverage of the partitions its posting list touches (score) -- and leaves a word untouched whose
+// live postings lie in none of those partitions.  So if w2 is untouched by w1 it is the winner of the next
+// iteration with the frequency it has now, w3 is the one after that if untouched by w1 and w2, and so on; the
+// first touched word ends the prefix, because its new place in the order is unknown.  With 119 partitions of
+// near-equal words a prefix runs until it meets a partition for the second time: about 14 winners per
+// iteration, 50 iterations where the one-winner loop needed 656.
+//   k_score        every block reads the candidates, finds the maximum and the set E of words at the top of the
+//                  order -- all words with count >= some c, about kETarget of them, never cutting through a run of
+//                  equal counts -- and scores its share of E: tie score, bitmap of the partitions of its live
+//                  postings, bitmap of the partitions of all its postings.
+//   k_prefix       one block: ranks E, takes the longest prefix whose words are untouched by the ones before
+//                  them, applies the reference's stop rules winner by winner (main.rs:344-366, :387-390), records
+//                  the winners and bumps the partition coverage.
+//   k_cover_multi  covers the segments of all the winners and takes the live ones off the counts of their words.
+// When the maximum falls below theta, k_prefix asks for a new candidate list (need_rebuild = 1): the next
+// iteration's k_max_count<true> + k_collect_cand, no-ops otherwise, rebuild it.
 constexpr unsigned kCandCap = 32768;   // longer lists go the five-launch way: every block reads all of it
 constexpr int kSelectGrid = 128;
-constexpr int kOwn = (int)(kCandCap / kSelectGrid);   // a block's share of the tied words fits: no second pass
-constexpr int kNarrowMaxP = 8192;      // 17 partition bitmaps in LDS
+constexpr int kEMax = 2048;            // words scored per iteration at most (more words tied at the maximum: five-launch way)
+constexpr int kETarget = 128;          // ... and aimed at
+constexpr int kOwn = kEMax / kSelectGrid;   // a block's share of E per class
+constexpr int kMaxPick = 64;           // winners per iteration at most
+constexpr int kHistBins = 256;         // counts from the maximum down that E may reach
+constexpr int kNarrowMaxP = 8192;      // 34 partition bitmaps in LDS
 
-__global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *count, const uint32_t *cand,
-                                                 const uint32_t *post_off, const uint32_t *post,
-                                                 const uint8_t *ignored, const uint32_t *coverage, int P, int G,
-                                                 int parity)
+struct PickState {
+    int fast_done;           // k_fast dealt with this iteration: k_score / k_prefix have nothing to do
+    int valid;               // k_score ran to its end in this iteration (k_prefix takes it back)
+    int m;                   // the candidates' maximum count
+    unsigned tot_l, tot_s;   // words of E with long / short posting lists: result slots [0, tot_l) and [kEMax - tot_s, kEMax)
+    int want_rebuild;        // the maximum fell below theta: a word outside the list may be ahead
+    int too_many;            // list longer than kCandCap, or more than kEMax words tied at the maximum
+    unsigned n_pick;         // winners of this iteration (k_prefix)
+    unsigned n_chunks;       // 64-posting chunks of all of them
+    uint32_t kid[kMaxPick];
+    uint32_t cum[kMaxPick + 1];   // chunks of the winners before winner j
+};
+
+// The iteration's fast path: no posting walks but for a handful of words.  Nearly every word's postings lie in ONE
+// partition (the same window of many genomes); word_part / word_multi say which, and for which words that is not so.
+// For one-partition words the loop's order needs no walk: within a partition all of them have the same tie score,
+// 1 / (coverage + 1) (one live partition: main.rs:268-282), so a partition's best word -- its LEADER -- is the one
+// with the highest count, smallest word first; and covering a word changes nothing but the words of the partitions
+// its postings lie in and those partitions' coverage.  The greedy order is therefore a merge of per-partition
+// sequences, and a whole run of it can be read off an ordered list of the leaders and of the (few) candidates with
+// postings in several partitions, for which k_multi has walked the postings (live postings per partition in
+// first-seen order, hence the exact tie score; all partitions).  Walk that list in the loop's order (count, score,
+// word); keep, per partition p touched by an accepted word, ub[p] = the live segments p has left, an upper bound
+// on the new count of anything that lives in p; then
+//   * an entry none of whose partitions is touched has the key it had: it is the next winner if its count is above
+//     `bound`, the largest count anything passed over or left behind can still have;
+//   * an entry with a touched partition is passed over, and what it can still have (its live postings in untouched
+//     partitions + min(its postings, ub) in touched ones) goes into `bound`;
+//   * every other word stands behind its partition's leader, or in a touched partition (<= ub[p] <= bound).
+// In the first iterations that is every partition's leader at once (119 winners in two iterations of 64).  An
+// entry the fast path cannot judge (a word with more than kMultiParts partitions at the top, too many such
+// candidates, P above kFastMaxP) leaves the iteration to k_score / k_prefix, which walk whatever they need.
+constexpr int kFastMaxP = 2048;    // entries ranked by counting, n^2 / 1024 steps per thread
+constexpr int kMultiParts = 4;     // partitions of a several-partition word the fast path keeps
+constexpr int kFastTop = 256;      // entries of the order the walk may look at (accepted + passed over)
+constexpr int kFastEnt = kFastMaxP + (int)kMaxMulti;
+
+constexpr int kMinorSegs = 4;      // a partition with at most this many live postings of the word: their segments are kept
+
+struct MultiInfo {   // k_multi's result for mcand[j]
+    uint32_t kid;
+    int count;                                  // live postings = sum of live_cnt
+    unsigned char n_live, n_all, overflow, pad; // overflow: more partitions than kMultiParts (live or all)
+    unsigned short live_part[kMultiParts];      // in first-seen order of the live postings (ascending segment index)
+    unsigned short all_part[kMultiParts];
+    int live_cnt[kMultiParts];
+    uint32_t first_seg[kMultiParts];            // the first live posting (segment index) of each live partition
+    uint32_t seg[kMultiParts][kMinorSegs];      // live_cnt <= kMinorSegs: the live postings themselves, ascending
+};
+
+// One block per several-partition candidate: per-partition tallies of its live postings, the segment at which each
+// partition is first seen live, the set of all its partitions, and the live postings of the partitions that hold
+// only a few of them.
+__global__ void __launch_bounds__(1024) k_multi(const Status *st, const uint32_t *mcand, const uint32_t *post_off,
+                                                const uint32_t *post, const uint8_t *ignored, int P, int G,
+                                                MultiInfo *out)
+{
+    __shared__ int cnt[kFastMaxP];
+    __shared__ unsigned first[kFastMaxP];
+    __shared__ unsigned allb[kFastMaxP / 32];
+    __shared__ int n_l, n_a;
+    __shared__ unsigned short lp[8], ap[8];
+    __shared__ int lc[8], nseg[8];
+    __shared__ unsigned lf[8];
+    __shared__ uint32_t segs[8][kMinorSegs];
+    const unsigned n = st->n_mcand;   // (this kernel writes no flag)
+    if (st->stop || st->need_rebuild == 1 || st->want_general || n > kMaxMulti || P > kFastMaxP) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (unsigned j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint32_t kid = mcand[j];
+        for (int e = tid; e < P; e += 1024) {
+            cnt[e] = 0;
+            first[e] = 0xffffffffu;
+        }
+        if (tid < kFastMaxP / 32) allb[tid] = 0u;
+        if (tid < 8) nseg[tid] = 0;
+        if (tid == 0) n_l = n_a = 0;
+        __syncthreads();
+        const uint32_t b = post_off[kid], e = post_off[kid + 1];
+        for (uint32_t base = b; base < e; base += 4096) {
+            uint32_t seg[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = base + u * 1024 + tid;
+                seg[u] = i < e ? post[i] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                live[u] = seg[u] != 0xffffffffu && !ignored[row_of(seg[u], (uint32_t)P, (uint32_t)G)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int part = seg[u] != 0xffffffffu ? (int)(seg[u] % (uint32_t)P) : -1;
+                unsigned long long m = __ballot(part >= 0);
+                while (m) {   // wave-uniform: once per distinct partition of the wave's 64 postings
+                    const int l = __ffsll((long long)m) - 1;
+                    const int pl = __builtin_amdgcn_readlane(part, l);
+                    const unsigned long long same = __ballot(part == pl);
+                    const unsigned long long lives = __ballot(live[u] && part == pl);
+                    if (lives) {   // wave-uniform
+                        const uint32_t fs = (uint32_t)__builtin_amdgcn_readlane((int)seg[u], __ffsll((long long)lives) - 1);
+                        if (lane == l) {
+                            atomicAdd(&cnt[pl], (int)__popcll(lives));
+                            atomicMin(&first[pl], fs);   // postings ascend: the lowest live lane holds the wave's first
+                        }
+                    }
+                    if (lane == l) atomicOr(&allb[pl >> 5], 1u << (pl & 31));
+                    m &= ~same;
+                }
+            }
+        }
+        __syncthreads();
+        for (int p0 = tid; p0 < P; p0 += 1024) {
+            if (cnt[p0] > 0) {
+                const int at = atomicAdd(&n_l, 1);
+                if (at < 8) {
+                    lp[at] = (unsigned short)p0;
+                    lc[at] = cnt[p0];
+                    lf[at] = first[p0];
+                }
+            }
+            if ((allb[p0 >> 5] >> (p0 & 31)) & 1u) {
+                const int at = atomicAdd(&n_a, 1);
+                if (at < 8) ap[at] = (unsigned short)p0;
+            }
+        }
+        __syncthreads();
+        const int nl = min(n_l, 8);
+        // second look at the postings for the partitions with a few live ones: which segments they are
+        bool any_minor = false;
+        for (int x = 0; x < nl; ++x) any_minor = any_minor || lc[x] <= kMinorSegs;
+        if (any_minor && n_l <= kMultiParts) {   // block-uniform
+            for (uint32_t i = b + tid; i < e; i += 1024) {
+                const uint32_t sg = post[i];
+                const int part = (int)(sg % (uint32_t)P);
+                if (cnt[part] <= kMinorSegs && !ignored[row_of(sg, (uint32_t)P, (uint32_t)G)]) {
+                    int x = 0;
+                    while (x < nl && lp[x] != (unsigned short)part) ++x;
+                    const int at = atomicAdd(&nseg[x], 1);
+                    if (at < kMinorSegs) segs[x][at] = sg;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            MultiInfo mi;
+            mi.kid = kid;
+            mi.pad = 0;
+            mi.overflow = (n_l > kMultiParts || n_a > kMultiParts) ? 1 : 0;
+            mi.n_live = (unsigned char)min(n_l, kMultiParts);
+            mi.n_all = (unsigned char)min(n_a, kMultiParts);
+            int order[8];
+            for (int x = 0; x < nl; ++x) order[x] = x;
+            for (int x = 1; x < nl; ++x)   // first-seen order (a handful of entries)
+                for (int y = x; y > 0 && lf[order[y]] < lf[order[y - 1]]; --y) {
+                    const int t = order[y];
+                    order[y] = order[y - 1];
+                    order[y - 1] = t;
+                }
+            int total = 0;
+            for (int x = 0; x < kMultiParts; ++x) {
+                const int o = x < nl ? order[x] : 0;
+                mi.live_part[x] = x < nl ? lp[o] : (unsigned short)0;
+                mi.live_cnt[x] = x < nl ? lc[o] : 0;
+                mi.first_seg[x] = x < nl ? lf[o] : 0u;
+                mi.all_part[x] = x < min(n_a, 8) ? ap[x] : (unsigned short)0;
+                for (int q = 0; q < kMinorSegs; ++q) mi.seg[x][q] = 0u;
+                if (x < nl && lc[o] <= kMinorSegs) {
+                    uint32_t v[kMinorSegs];
+                    const int ns = min(nseg[o], kMinorSegs);
+                    for (int q = 0; q < ns; ++q) v[q] = segs[o][q];
+                    for (int q = 1; q < ns; ++q)   // ascending
+                        for (int y = q; y > 0 && v[y] < v[y - 1]; --y) {
+                            const uint32_t t = v[y];
+                            v[y] = v[y - 1];
+                            v[y - 1] = t;
+                        }
+                    for (int q = 0; q < ns; ++q) mi.seg[x][q] = v[q];
+                }
+            }
+            for (int x = 0; x < nl; ++x) total += lc[x];
+            mi.count = total;
+            out[j] = mi;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kFastTasks = 1024;   // (candidate, minor partition, segment) checks of one iteration
+constexpr int kMaxPend = 8;        // several-partition words waiting with a re-computed key
+constexpr uint32_t kByMulti = 0xffffffffu;
+
+// A several-partition word some of whose partitions were touched by winners of this iteration.  If every such
+// partition either holds no live posting of the word, or holds a few (<= kMinorSegs) and was touched by nothing but
+// its partition's one-partition leader, the word's new key is exact: the leader took the segments that hold it
+// (hit bits, found before the walk from the segments' word lists), the rest stay, the partition's coverage is one up.
+struct WalkWord {
+    int ent;                  // entry index
+    int j;                    // index into multi[]
+    int cnt[kMultiParts];     // live postings left per live partition
+    unsigned rem;             // 4 bits per live partition: which of its kept segments are left
+    unsigned char seen[kMultiParts];   // per all_part: the partition's touch count the key accounts for
+    unsigned long long key;   // count << 32 | score bits, as of now
+};
+
+__global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const int32_t *count, const uint32_t *cand,
+                                               const uint16_t *word_part, const uint8_t *word_multi,
+                                               const MultiInfo *multi, const int32_t *live_part, uint32_t *coverage,
+                                               const uint32_t *post_off, const uint64_t *ukeys,
+                                               const int32_t *kid_of_inst, int per, int G, uint64_t *out_key,
+                                               uint32_t *out_freq, uint32_t *out_trace, int P)
+{
+    __shared__ unsigned long long lead[kFastMaxP];   // per partition: count << 32 | ~word id of its one-partition leader
+    __shared__ unsigned long long lkey[kFastEnt];    // entries: count << 32 | score bits
+    __shared__ uint32_t lkid[kFastEnt];
+    __shared__ unsigned short lwho[kFastEnt];        // partition of a leader, or 0x8000 | index of a several-partition candidate
+    __shared__ int ub[kFastMaxP];                    // live segments left in a partition touched in this iteration, -1: untouched
+    __shared__ uint32_t who[kFastMaxP];              // the one-partition winner that touched it, kByMulti: something else did
+    __shared__ unsigned char tcount[kFastMaxP], cov_add[kFastMaxP];   // touches / coverage bumps of this iteration
+    __shared__ unsigned hitmask[kMaxMulti];          // bit 4 x + q: segment q of live partition x holds that partition's leader
+    __shared__ unsigned char hit_known[kMaxMulti];
+    __shared__ uint32_t task_row[kFastTasks], task_kid[kFastTasks];
+    __shared__ unsigned short task_bit[kFastTasks], task_j[kFastTasks];
+    __shared__ int top[kFastTop];
+    __shared__ unsigned short bump[kMaxPick * kMultiParts];   // partitions whose coverage goes up
+    __shared__ int red[16];
+    __shared__ int n_ent_sh, n_bump, n_task;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (single block, and the only writer of the loop's flags besides k_prefix, which does not run when this did)
+    const int stop = st->stop, rebuild_state = st->need_rebuild;
+    const unsigned n_cand = st->n_cand, n_mcand = st->n_mcand;
+    const int theta = st->theta, n_win0 = st->n_win, max_iter = st->max_iter, stop_next0 = st->stop_next;
+    const int want_general0 = st->want_general;
+    __syncthreads();
+    if (tid == 0) {
+        ps->fast_done = 1;
+        ps->valid = 0;
+        ps->want_rebuild = 0;
+        ps->too_many = 0;
+        ps->n_pick = 0;
+        ps->n_chunks = 0;
+        n_ent_sh = 0;
+        n_bump = 0;
+        n_task = 0;
+    }
+    if (stop || rebuild_state == 1 || want_general0) {   // the host looks at these between batches
+        if (tid == 0) st->it_idle += 1;
+        return;
+    }
+    if (tid == 0 && rebuild_state == 2) {   // the list was rebuilt just before this iteration
+        st->need_rebuild = 0;
+        st->it_rebuild += 1;
+    }
+    if (n_win0 >= max_iter || stop_next0) {   // main.rs:344-366: the loop head
+        if (tid == 0) st->stop = 1;
+        return;
+    }
+    if (n_cand > kCandCap) {   // a list this long goes the five-launch way
+        if (tid == 0) {
+            st->need_rebuild = 1;
+            st->too_many = 1;
+        }
+        return;
+    }
+    if (P > kFastMaxP || n_mcand > kMaxMulti) {
+        if (tid == 0) {
+            ps->fast_done = 0;
+            st->want_general = 1;
+        }
+        return;
+    }
+    for (int e = tid; e < P; e += 1024) {
+        lead[e] = 0ull;
+        ub[e] = -1;
+        who[e] = kByMulti;
+        tcount[e] = 0;
+        cov_add[e] = 0;
+    }
+    for (unsigned e = (unsigned)tid; e < n_mcand; e += 1024) {
+        hitmask[e] = 0u;
+        hit_known[e] = 1;
+    }
+    __syncthreads();
+    int m = 0;   // highest count of all the candidates
+    for (unsigned i = (unsigned)tid; i < n_cand; i += 1024) {
+        const uint32_t kid = cand[i] & ~kCandLong;
+        const int c = count[kid];
+        m = max(m, c);
+        if (!word_multi[kid] && c > 0)
+            atomicMax(&lead[word_part[kid]], ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(0xffffffffu - kid));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+    if (m < theta) {   // a word outside the list may be ahead now
+        if (tid == 0) st->need_rebuild = 1;
+        return;
+    }
+    // the entries: leaders with a count of at least theta (nothing below it may be accepted from this list) ...
+    for (int p0 = 0; p0 < P; p0 += 1024) {
+        const int p = p0 + tid;
+        const unsigned long long l = p < P ? lead[p] : 0ull;
+        const bool have = (int)(l >> 32) >= theta;
+        const unsigned long long mk = __ballot(have);
+        int base = 0;
+        if (mk && lane == 0) base = atomicAdd(&n_ent_sh, (int)__popcll(mk));
+        base = __shfl(base, 0);
+        if (have) {
+            const int at = base + (int)__popcll(mk & ((1ull << lane) - 1ull));
+            lkey[at] = (l & 0xffffffff00000000ull) | (unsigned long long)__float_as_uint(1.0f / ((float)coverage[p] + 1.0f));
+            lkid[at] = 0xffffffffu - (uint32_t)(l & 0xffffffffull);
+            lwho[at] = (unsigned short)p;
+        }
+    }
+    // ... and the several-partition candidates with theirs: the score as partition_tie_score adds it up, in f32, one term
+    // per live partition in first-seen order (an overflowing one gets no score: the walk stops at it).  For each of
+    // their partitions with a few live postings: does a segment hold that partition's leader?  (One check per
+    // segment and window position, all of them in flight together.)
+    for (unsigned j = (unsigned)tid; j < n_mcand; j += 1024) {
+        const MultiInfo &mi = multi[j];
+        const int mcount = mi.overflow ? count[mi.kid] : mi.count;   // (an overflowing word's tallies are not all kept)
+        if (mcount >= theta) {
+            float acc = 0.0f;
+            for (int x = 0; x < mi.n_live; ++x) acc += 1.0f / ((float)coverage[mi.live_part[x]] + 1.0f);
+            // (a word with more partitions than are kept has no score here: it goes in front of everything of its
+            //  count, where the walk stops at it before it could accept a word that word may be ahead of)
+            if (mi.overflow) acc = __uint_as_float(0x7f7fffffu);
+            const int at = atomicAdd(&n_ent_sh, 1);
+            lkey[at] = ((unsigned long long)(unsigned)mcount << 32) | (unsigned long long)__float_as_uint(acc);
+            lkid[at] = mi.kid;
+            lwho[at] = (unsigned short)(0x8000u | j);
+            if (!mi.overflow)
+                for (int x = 0; x < mi.n_live; ++x) {
+                    const int p = mi.live_part[x];
+                    if (mi.live_cnt[x] > kMinorSegs || (int)(lead[p] >> 32) < theta) continue;   // no leader that could touch it
+                    for (int q = 0; q < mi.live_cnt[x]; ++q) {
+                        const int at2 = atomicAdd(&n_task, 1);
+                        if (at2 < kFastTasks) {
+                            task_row[at2] = row_of(mi.seg[x][q], (uint32_t)P, (uint32_t)G);
+                            task_kid[at2] = 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull);
+                            task_bit[at2] = (unsigned short)(4 * x + q);
+                            task_j[at2] = (unsigned short)j;
+                        } else {
+                            hit_known[j] = 0;
+                        }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    {
+        const int nt = min(n_task, kFastTasks);
+        for (int id = tid; id < nt * per; id += 1024) {
+            const int t = id / per, q = id - t * per;
+            if ((uint32_t)kid_of_inst[(size_t)task_row[t] * per + q] == task_kid[t]) atomicOr(&hitmask[task_j[t]], 1u << task_bit[t]);
+        }
+    }
+    const int n_ent = n_ent_sh;
+    for (int i = tid; i < n_ent; i += 1024) {   // rank by counting; equal (count, score): the smaller word first
+        const unsigned long long ki = lkey[i];
+        const uint32_t di = lkid[i];
+        int rank = 0;
+        for (int j = 0; j < n_ent; ++j) {
+            const unsigned long long kj = lkey[j];
+            rank += (kj > ki || (kj == ki && lkid[j] < di)) ? 1 : 0;
+        }
+        if (rank < kFastTop) top[rank] = i;
+    }
+    __syncthreads();
+    {
+        // The walk below is one thread's, and every global load in it would be a dependent one: all the threads touch what
+        // it will read (the entries' words, posting offsets and several-partition records, the partitions' live counts and
+        // coverage) so that it finds them in this CU's L1.
+        unsigned sink = 0;
+        const int lim = min(n_ent, kFastTop);
+        for (int r = tid; r < lim; r += 1024) {
+            const int i = top[r];
+            const uint32_t kid = lkid[i];
+            sink += (unsigned)ukeys[kid] + post_off[kid] + post_off[kid + 1];
+            if (lwho[i] & 0x8000u) {
+                const unsigned *mp = reinterpret_cast<const unsigned *>(&multi[lwho[i] & 0x7fffu]);
+                sink += mp[0] + mp[16] + mp[sizeof(MultiInfo) / 4 - 1];
+            }
+        }
+        for (int p = tid; p < P; p += 1024) sink += (unsigned)live_part[p] + coverage[p];
+        if (sink == 0x9e3779b9u) red[0] = (int)sink;   // (keeps the loads)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n_win = n_win0, np = 0, nb = 0, stop_next = stop_next0, stop_now = 0, bound = 0;
+        unsigned chunks = 0;
+        const int min_freq = st->min_freq, limit = min(n_ent, kFastTop);
+        WalkWord pend[kMaxPend];
+        int npend = 0, r = 0;
+        while (np < kMaxPick) {
+            // the next entry of the order: the list's, or a waiting word whose new key is ahead of it
+            int pk = -1;
+            for (int q = 0; q < npend; ++q)
+                if (pk < 0 || pend[q].key > pend[pk].key ||
+                    (pend[q].key == pend[pk].key && lkid[pend[q].ent] < lkid[pend[pk].ent]))
+                    pk = q;
+            const int mi_i = r < limit ? top[r] : -1;
+            if (pk < 0 && mi_i < 0) break;
+            bool from_pend = mi_i < 0;
+            if (pk >= 0 && mi_i >= 0)
+                from_pend = pend[pk].key > lkey[mi_i] || (pend[pk].key == lkey[mi_i] && lkid[pend[pk].ent] < lkid[mi_i]);
+            WalkWord w;
+            if (from_pend) {
+                w = pend[pk];
+                pend[pk] = pend[--npend];
+            } else {
+                ++r;
+                w.ent = mi_i;
+                w.key = lkey[mi_i];
+                w.j = (lwho[mi_i] & 0x8000u) ? (int)(lwho[mi_i] & 0x7fffu) : -1;
+                w.rem = 0xffffu;
+                for (int x = 0; x < kMultiParts; ++x) {
+                    w.cnt[x] = w.j >= 0 ? multi[w.j].live_cnt[x] : 0;
+                    w.seen[x] = 0;
+                }
+            }
+            const int f = (int)(w.key >> 32);
+            const uint32_t kid = lkid[w.ent];
+            const MultiInfo *mi = w.j >= 0 ? &multi[w.j] : nullptr;
+            if (!mi) {   // a partition's leader
+                const int p = lwho[w.ent];
+                if (ub[p] >= 0) {   // its partition was touched: it is passed over, with what it can still have
+                    bound = max(bound, min(f, ub[p]));
+                    continue;
+                }
+            } else {
+                if (mi->overflow) break;   // the fast path cannot judge this word: nothing behind it is safe
+                bool need = false, bad = false;
+                for (int x = 0; x < mi->n_all; ++x) need = need || tcount[mi->all_part[x]] != w.seen[x];
+                if (need) {
+                    for (int x = 0; x < mi->n_all && !bad; ++x) {
+                        const int p = mi->all_part[x];
+                        if (tcount[p] == w.seen[x]) continue;
+                        int xl = -1;
+                        for (int y = 0; y < mi->n_live; ++y)
+                            if (mi->live_part[y] == p) xl = y;
+                        if (xl >= 0 && w.cnt[xl] > 0) {
+                            // live postings in a touched partition: exact only for a few of them against the partition's leader
+                            if (mi->live_cnt[xl] > kMinorSegs || tcount[p] != 1 || w.seen[x] != 0 || who[p] == kByMulti ||
+                                who[p] != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull) || !hit_known[w.j]) {
+                                bad = true;
+                                break;
+                            }
+                            const unsigned hits = (hitmask[w.j] >> (4 * xl)) & ((1u << mi->live_cnt[xl]) - 1u);
+                            w.rem &= ~(hits << (4 * xl));
+                            w.cnt[xl] -= (int)__popc(hits);
+                        }
+                        w.seen[x] = tcount[p];
+                    }
+                    if (bad) {   // passed over with what it can still have
+                        int still = 0;
+                        for (int y = 0; y < mi->n_live; ++y) {
+                            const int u = ub[mi->live_part[y]];
+                            still += u >= 0 ? min(w.cnt[y], u) : w.cnt[y];
+                        }
+                        bound = max(bound, still);
+                        continue;
+                    }
+                    // its key as of now: the live partitions in first-seen order, the coverage as this iteration leaves it
+                    int total = 0, ord[kMultiParts], no = 0;
+                    uint32_t fs[kMultiParts];
+                    for (int y = 0; y < mi->n_live; ++y) {
+                        if (w.cnt[y] <= 0) continue;
+                        total += w.cnt[y];
+                        uint32_t f0 = mi->first_seg[y];
+                        if (mi->live_cnt[y] <= kMinorSegs) {
+                            const unsigned left = (w.rem >> (4 * y)) & 0xfu;
+                            f0 = mi->seg[y][__ffs((int)left) - 1];
+                        }
+                        int at = no++;
+                        while (at > 0 && fs[at - 1] > f0) {
+                            fs[at] = fs[at - 1];
+                            ord[at] = ord[at - 1];
+                            --at;
+                        }
+                        fs[at] = f0;
+                        ord[at] = y;
+                    }
+                    float acc = 0.0f;
+                    for (int q = 0; q < no; ++q) {
+                        const int p = mi->live_part[ord[q]];
+                        acc += 1.0f / ((float)(coverage[p] + (uint32_t)cov_add[p]) + 1.0f);
+                    }
+                    w.key = ((unsigned long long)(unsigned)total << 32) | (unsigned long long)__float_as_uint(acc);
+                    if (total >= theta) {
+                        if (npend < kMaxPend) pend[npend++] = w;
+                        else bound = max(bound, total);
+                    }
+                    continue;   // (below theta: behind everything this list may yield)
+                }
+            }
+            if (f <= bound) break;   // something passed over or left behind may be ahead: the next iteration decides
+            if (n_win >= max_iter || stop_next) {   // main.rs:344: the loop head
+                stop_now = 1;
+                break;
+            }
+            if (f <= 1) {   // main.rs:353-366 (cannot happen: f >= theta >= 2)
+                stop_now = 1;
+                break;
+            }
+            out_key[n_win] = ukeys[kid];
+            out_freq[n_win] = (uint32_t)f;
+            // trace: iteration (fast + general + 1) << 8 | 1 leader, 2 several-partition word, 3 the same after a re-computed key
+            out_trace[n_win] = ((uint32_t)(st->it_fast + st->it_general + 1) << 8) | (mi ? (from_pend ? 3u : 2u) : 1u);
+            ++n_win;
+            ps->kid[np] = kid;
+            ps->cum[np] = chunks;
+            chunks += (post_off[kid + 1] - post_off[kid] + 63u) / 64u;
+            ++np;
+            if (f < min_freq) stop_next = 1;   // main.rs:387-390: stop after the push
+            if (mi) {
+                // partitions it only has covered segments in lose nothing, but their coverage goes up
+                for (int x = 0; x < mi->n_all; ++x) {
+                    const int p = mi->all_part[x];
+                    if (ub[p] < 0) ub[p] = live_part[p];
+                    who[p] = kByMulti;
+                    tcount[p] = (unsigned char)min(255, tcount[p] + 1);
+                    cov_add[p] += 1;
+                    bump[nb++] = (unsigned short)p;
+                }
+                for (int y = 0; y < mi->n_live; ++y)
+                    if (w.cnt[y] > 0) ub[mi->live_part[y]] -= w.cnt[y];
+                // what a word living in one of these partitions can still have: no more than the partition has left,
+                // and no more than it had (its partition's leader's count, or less than theta if it is not on the list)
+                for (int x = 0; x < mi->n_all; ++x) {
+                    const int p = mi->all_part[x];
+                    bound = max(bound, min(ub[p], max((int)(lead[p] >> 32), theta - 1)));
+                }
+            } else {
+                const int p = lwho[w.ent];
+                ub[p] = live_part[p] - f;
+                who[p] = kid;
+                tcount[p] = 1;
+                cov_add[p] += 1;
+                bound = max(bound, ub[p]);
+                bump[nb++] = (unsigned short)p;
+            }
+        }
+        ps->cum[np] = chunks;
+        ps->n_pick = (unsigned)np;
+        ps->n_chunks = chunks;
+        st->n_win = n_win;
+        st->stop_next = stop_next;
+        if (stop_now) st->stop = 1;
+        if (np) st->winner = (int)ps->kid[np - 1];
+        st->maxf = 0;
+        if (np == 0 && !stop_now) {   // left to k_score / k_prefix
+            ps->fast_done = 0;
+            st->want_general = 1;
+        }
+        if (np) st->it_fast += 1;
+        n_bump = nb;
+    }
+    __syncthreads();
+    if (tid < n_bump) atomicAdd(&coverage[bump[tid]], 1u);   // main.rs:371-378: once per partition of a winner's posting list
+}
+
+__global__ void __launch_bounds__(1024) k_score(const Status *st, PickState *ps, const int32_t *count,
+                                                const uint32_t *cand, const uint32_t *post_off, const uint32_t *post,
+                                                const uint8_t *ignored, const uint32_t *coverage, int P, int G,
+                                                unsigned long long *res_key, uint32_t *res_kid, unsigned *res_bits)
 {
     constexpr int kKeep = 4;   // rounds of 1024 candidates whose (word, count) stay in registers
     extern __shared__ unsigned char smem[];
     __shared__ int red[16];
-    __shared__ unsigned wl[kKeep * 16], ws[kKeep * 16];   // tied words per (round, wave), then their prefix sums
+    __shared__ unsigned wl[kKeep * 16], ws[kKeep * 16];   // E's words per (round, wave), then their prefix sums
     __shared__ unsigned tot_sh[2];
     __shared__ uint32_t own_long[kOwn], own_short[kOwn];
+    __shared__ unsigned hist[kHistBins];
+    __shared__ int sel_sh[2];   // deepest bin of E, its size
+    __shared__ int go_sh;
     __shared__ TieBlockShared tb;
-    // stop / need_rebuild are written by block 0 of this very kernel as well: every block reaches the same
-    // verdict from the same inputs, so a block that sees the flag early only skips work it would have skipped
-    if (st->stop || st->need_rebuild) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // the loop's flags once per block (this kernel writes none of them: k_prefix does)
+    if (tid == 0)
+        go_sh = st->want_general && !(st->stop || st->need_rebuild == 1 || st->n_win >= st->max_iter || st->stop_next);
+    if (tid < kHistBins) hist[tid] = 0u;
+    __syncthreads();
+    if (!go_sh) return;
     const int words = (P + 31) / 32;
-    unsigned *seen_blk = (unsigned *)smem;
-    unsigned *seen_w = seen_blk + (size_t)words * (1 + wave);
-    const int n_win = st->n_win;
-    if (n_win >= st->max_iter || st->stop_next) {   // main.rs:344-366
-        if (blockIdx.x == 0 && tid == 0) st->stop = 1;
-        return;
-    }
+    unsigned *seen_blk = (unsigned *)smem, *all_blk = seen_blk + words;
+    unsigned *seen_w = all_blk + (size_t)words * (1 + 2 * wave), *all_w = seen_w + words;
     const unsigned n_cand = st->n_cand;
+    const int theta = st->theta;
     if (n_cand > kCandCap) {   // every block reads the whole list: too long for that, the host goes the other way
         if (blockIdx.x == 0 && tid == 0) {
-            st->need_rebuild = 1;
-            st->too_many = 1;
+            ps->too_many = 1;
+            ps->valid = 1;
         }
         return;
     }
@@ -570,17 +1285,70 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
     m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = max(m, red[w]);
-    if (m < st->theta) {   // a word outside the list may be ahead now
-        if (blockIdx.x == 0 && tid == 0) st->need_rebuild = 1;
+    if (m < theta) {   // a word outside the list may be ahead now
+        if (blockIdx.x == 0 && tid == 0) {
+            ps->want_rebuild = 1;
+            ps->valid = 1;
+        }
+        return;
+    }
+    // E = the words with count >= m - d for the largest d that keeps |E| <= kETarget and the counts >= theta;
+    // d = 0 (the words tied at the maximum) whatever their number
+#pragma unroll
+    for (int r = 0; r < kKeep; ++r)
+        if (ck[r] != 0xffffffffu && m - cc[r] < kHistBins) atomicAdd(&hist[m - cc[r]], 1u);
+    for (unsigned i = kKeep * 1024u + (unsigned)tid; i < n_cand; i += 1024) {
+        const int d = m - count[cand[i] & ~kCandLong];
+        if (d < kHistBins) atomicAdd(&hist[d], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = hist[lane * 4 + q];
+            sum += v[q];
+        }
+        unsigned incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        unsigned run = incl - sum;
+        int ok = 0;   // bins of this lane that E may reach (the admissible bins are a prefix of all the bins)
+        unsigned cum_at[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += v[q];
+            cum_at[q] = run;
+            const int bin = lane * 4 + q;
+            ok += (bin == 0 || (run <= (unsigned)kETarget && m - bin >= theta)) ? 1 : 0;
+        }
+        int total = ok;
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        const int dsel = total - 1;   // >= 0: bin 0 always counts
+        if (lane == (dsel >> 2)) {
+            sel_sh[0] = dsel;
+            sel_sh[1] = (int)cum_at[dsel & 3];
+        }
+    }
+    __syncthreads();
+    const int dsel = sel_sh[0];
+    if (sel_sh[1] > kEMax) {   // (only possible with d = 0) more words tied at the maximum than one iteration scores
+        if (blockIdx.x == 0 && tid == 0) {
+            ps->too_many = 1;
+            ps->valid = 1;
+        }
         return;
     }
     const unsigned long long below = (1ull << lane) - 1ull;
-    // number the tied words (long and short posting lists apart) in list order; word t of a class belongs
-    // to block t % gridDim.x, which keeps its share in own_long / own_short
+    // number E's words (long and short posting lists apart) in list order; word t of a class belongs to block
+    // t % gridDim.x, which keeps its share in own_long / own_short, and owns result slot t (long) or
+    // kEMax - 1 - t (short)
     unsigned long long bl[kKeep], bs[kKeep];
 #pragma unroll
     for (int r = 0; r < kKeep; ++r) {
-        const bool hit = cc[r] == m;   // m >= 2: the padding (count 0) never hits
+        const bool hit = ck[r] != 0xffffffffu && m - cc[r] <= dsel;
         const bool lg = hit && (ck[r] & kCandLong);
         bl[r] = __ballot(lg);
         bs[r] = __ballot(hit && !lg);
@@ -608,11 +1376,9 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
         }
     }
     __syncthreads();
-    const unsigned keep_l = tot_sh[0], keep_s = tot_sh[1];
-    unsigned long long best = 0;
 #pragma unroll
     for (int r = 0; r < kKeep; ++r) {
-        const bool hit = cc[r] == m;
+        const bool hit = ck[r] != 0xffffffffu && m - cc[r] <= dsel;
         if (hit) {
             const bool lg = (ck[r] & kCandLong) != 0;
             const unsigned t = lg ? wl[r * 16 + wave] + (unsigned)__popcll(bl[r] & below)
@@ -620,103 +1386,281 @@ __global__ void __launch_bounds__(1024) k_select(Status *st, const int32_t *coun
             if (t % gridDim.x == blockIdx.x) (lg ? own_long : own_short)[t / gridDim.x] = ck[r] & ~kCandLong;
         }
     }
-    unsigned tot_l = keep_l, tot_s = keep_s;
+    unsigned tot_l = tot_sh[0], tot_s = tot_sh[1];
     for (unsigned base = kKeep * 1024u; base < n_cand; base += 1024) {   // the rest of a long list
         const unsigned i = base + (unsigned)tid;
         uint32_t kid = 0;
         bool hit = false, lg = false;
         if (i < n_cand) {
             kid = cand[i];
-            hit = count[kid & ~kCandLong] == m;
+            hit = m - count[kid & ~kCandLong] <= dsel;
             lg = hit && (kid & kCandLong);
         }
         const unsigned long long xl = __ballot(lg), xs = __ballot(hit && !lg);
         __syncthreads();   // red is read by everybody before it is rewritten
         if (lane == 0) red[wave] = (int)((unsigned)__popcll(xl) << 16 | (unsigned)__popcll(xs));
         __syncthreads();
-        unsigned pl = tot_l, ps = tot_s;
+        unsigned pl = tot_l, pss = tot_s;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
             const unsigned v = (unsigned)red[w];
             if (w < wave) {
                 pl += v >> 16;
-                ps += v & 0xffffu;
+                pss += v & 0xffffu;
             }
             tot_l += v >> 16;
             tot_s += v & 0xffffu;
         }
         if (hit) {
-            const unsigned t = lg ? pl + (unsigned)__popcll(xl & below) : ps + (unsigned)__popcll(xs & below);
+            const unsigned t = lg ? pl + (unsigned)__popcll(xl & below) : pss + (unsigned)__popcll(xs & below);
             if (t % gridDim.x == blockIdx.x) (lg ? own_long : own_short)[t / gridDim.x] = kid & ~kCandLong;
         }
     }
-    __syncthreads();   // the lists are complete
-    // t / gridDim.x < n_cand / gridDim.x <= kOwn: the share always fits
+    __syncthreads();   // the lists are complete (tot_l + tot_s = |E| <= kEMax: a block's share always fits)
     const unsigned nl = tot_l > blockIdx.x ? (tot_l - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const unsigned ns = tot_s > blockIdx.x ? (tot_s - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    if (tot_l + tot_s == 1) {   // a single candidate wins whatever its score
-        if (blockIdx.x == 0 && tid == 0) best = winner_key(1.0f, tot_l ? own_long[0] : own_short[0]);
-    } else {
-        for (unsigned j = 0; j < nl; ++j) {
-            const uint32_t kid = own_long[j];
-            tie_score_block(kid, seen_blk, &tb, words, post_off, post, ignored, coverage, P, G);
-            if (tid == 0) {
-                const unsigned long long key = winner_key(tb.acc, kid);
-                best = key > best ? key : best;
-            }
-            __syncthreads();
+    for (unsigned j = 0; j < nl; ++j) {
+        const uint32_t kid = own_long[j];
+        const unsigned slot = j * gridDim.x + blockIdx.x;
+        tie_score_block(kid, seen_blk, all_blk, &tb, words, post_off, post, ignored, coverage, P, G);
+        if (tid == 0) {
+            res_key[slot] = ((unsigned long long)(unsigned)count[kid] << 32) | (unsigned long long)__float_as_uint(tb.acc);
+            res_kid[slot] = kid;
         }
-        for (unsigned j = wave; j < ns; j += 16) {
-            const uint32_t kid = own_short[j];
-            const float acc = tie_score_wave(kid, seen_w, words, lane, post_off, post, ignored, coverage, P, G);
-            const unsigned long long key = winner_key(acc, kid);
-            best = key > best ? key : best;
+        for (int wd = tid; wd < words; wd += 1024) {
+            res_bits[((size_t)slot * 2) * words + wd] = seen_blk[wd];
+            res_bits[((size_t)slot * 2 + 1) * words + wd] = all_blk[wd];
+        }
+        __syncthreads();
+    }
+    for (unsigned j = wave; j < ns; j += 16) {
+        const uint32_t kid = own_short[j];
+        const unsigned slot = (unsigned)kEMax - 1u - (j * gridDim.x + blockIdx.x);
+        const float acc = tie_score_wave(kid, seen_w, all_w, words, lane, post_off, post, ignored, coverage, P, G);
+        if (lane == 0) {
+            res_key[slot] = ((unsigned long long)(unsigned)count[kid] << 32) | (unsigned long long)__float_as_uint(acc);
+            res_kid[slot] = kid;
+        }
+        for (int wd = lane; wd < words; wd += 64) {
+            res_bits[((size_t)slot * 2) * words + wd] = seen_w[wd];
+            res_bits[((size_t)slot * 2 + 1) * words + wd] = all_w[wd];
         }
     }
-    if (lane == 0 && best) atomicMax(&st->best2[parity], best);
     if (blockIdx.x == 0 && tid == 0) {
-        st->maxf = m;
-        st->it1 = (unsigned)n_win + 1u;
-        st->best2[parity ^ 1] = 0;   // the next iteration's; k_cover of the last one is over
+        ps->m = m;
+        ps->tot_l = tot_l;
+        ps->tot_s = tot_s;
+        ps->valid = 1;
     }
 }
 
-// Cover every segment that holds the winner: bump the partition coverage once per distinct
-// partition (main.rs:371-378, covered segments included) and, for segments covered now, take
-// one off the live count of every word they hold.
-// A block takes 64 postings at a time.  Wave 0 does the per-posting bookkeeping; the four waves
+// One block.  Ranks E by (count, score) descending and word ascending (= id ascending: ids follow the sorted key
+// order), takes the longest prefix of untouched words, applies the stop rules and records the winners.
+__global__ void __launch_bounds__(1024) k_prefix(Status *st, PickState *ps, const unsigned long long *res_key,
+                                                 const uint32_t *res_kid, const unsigned *res_bits,
+                                                 const uint32_t *post_off, const uint64_t *ukeys, uint32_t *coverage,
+                                                 uint64_t *out_key, uint32_t *out_freq, uint32_t *out_trace, int P)
+{
+    __shared__ unsigned long long key_s[kEMax];
+    __shared__ uint32_t kid_s[kEMax];
+    __shared__ unsigned short slot_s[kEMax];
+    __shared__ int top[kMaxPick + 1];   // position in key_s of the word of rank r
+    __shared__ int first_bad, n_acc;
+    const int tid = threadIdx.x;
+    const int words = (P + 31) / 32;
+    // (everything this kernel reads was written by earlier kernels; it is the only writer of the loop's flags)
+    const int valid = ps->valid, want_rebuild = ps->want_rebuild, too_many = ps->too_many;
+    const unsigned tot_l = ps->tot_l, tot_s = ps->tot_s;
+    const int stop = st->stop, rebuild_state = st->need_rebuild;
+    if (!st->want_general) return;   // block-uniform: only behind a k_fast that left the iteration to the walking path
+    __syncthreads();
+    if (tid == 0) st->want_general = 0;
+    if (tid == 0) {
+        ps->valid = 0;
+        ps->want_rebuild = 0;
+        ps->too_many = 0;
+        ps->n_pick = 0;
+        ps->n_chunks = 0;
+        first_bad = kMaxPick + 1;
+        n_acc = 0;
+    }
+    if (stop || rebuild_state == 1) return;
+    if (tid == 0 && rebuild_state == 2) st->need_rebuild = 0;   // the list was rebuilt at the head of this iteration
+    if (!valid) {
+        // k_score left at its loop-head test (main.rs:344-366): the loop is over
+        if (tid == 0 && (st->n_win >= st->max_iter || st->stop_next)) st->stop = 1;
+        return;
+    }
+    if (want_rebuild || too_many) {
+        if (tid == 0) {
+            st->need_rebuild = 1;
+            if (too_many) st->too_many = 1;
+        }
+        return;
+    }
+    const int n_e = (int)(tot_l + tot_s);
+    for (int i = tid; i < n_e; i += 1024) {
+        const unsigned slot = (unsigned)i < tot_l ? (unsigned)i : (unsigned)kEMax - 1u - ((unsigned)i - tot_l);
+        key_s[i] = res_key[slot];
+        kid_s[i] = res_kid[slot];
+        slot_s[i] = (unsigned short)slot;
+    }
+    __syncthreads();
+    // rank by counting (|E| is about a hundred; a few thousand only when that many words tie at the maximum)
+    for (int i = tid; i < n_e; i += 1024) {
+        const unsigned long long ki = key_s[i];
+        const uint32_t di = kid_s[i];
+        int rank = 0;
+        for (int j = 0; j < n_e; ++j) {
+            const unsigned long long kj = key_s[j];
+            rank += (kj > ki || (kj == ki && kid_s[j] < di)) ? 1 : 0;
+        }
+        if (rank <= kMaxPick) top[rank] = i;
+    }
+    __syncthreads();
+    const int n_top = min(n_e, kMaxPick + 1);
+    // first word of the order that an earlier one touches: live partitions of r against all partitions of q < r
+    for (int pr = tid; pr < n_top * n_top; pr += 1024) {
+        const int q = pr / n_top, r = pr % n_top;
+        if (q >= r || r >= first_bad) continue;
+        const unsigned *aq = res_bits + ((size_t)slot_s[top[q]] * 2 + 1) * words;
+        const unsigned *lr = res_bits + ((size_t)slot_s[top[r]] * 2) * words;
+        unsigned hit = 0;
+        for (int wd = 0; wd < words; ++wd) hit |= aq[wd] & lr[wd];
+        if (hit) atomicMin(&first_bad, r);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int limit = min(min(first_bad, n_top), kMaxPick);
+        int n_win = st->n_win, np = 0;
+        unsigned chunks = 0;
+        const int max_iter = st->max_iter, min_freq = st->min_freq;
+        int stop_next = st->stop_next, stop_now = 0;
+        for (int r = 0; r < limit; ++r) {
+            if (n_win >= max_iter || stop_next) {   // main.rs:344: the loop head
+                stop_now = 1;
+                break;
+            }
+            const int i = top[r];
+            const int f = (int)(key_s[i] >> 32);
+            if (f <= 1) {   // main.rs:353-366: no word, or the best word is in one segment only
+                stop_now = 1;
+                break;
+            }
+            const uint32_t kid = kid_s[i];
+            out_key[n_win] = ukeys[kid];
+            out_freq[n_win] = (uint32_t)f;
+            out_trace[n_win] = ((uint32_t)(st->it_fast + st->it_general + 1) << 8) | 4u;   // 4: after posting walks
+            ++n_win;
+            ps->kid[np] = kid;
+            ps->cum[np] = chunks;
+            chunks += (post_off[kid + 1] - post_off[kid] + 63u) / 64u;
+            ++np;
+            if (f < min_freq) stop_next = 1;   // main.rs:387-390: stop after the push
+        }
+        ps->cum[np] = chunks;
+        ps->n_pick = (unsigned)np;
+        ps->n_chunks = chunks;
+        st->n_win = n_win;
+        st->stop_next = stop_next;
+        if (stop_now) st->stop = 1;
+        if (np) st->winner = (int)ps->kid[np - 1];
+        st->maxf = 0;
+        if (np) st->it_general += 1;
+        n_acc = np;
+    }
+    __syncthreads();
+    // main.rs:371-378: the coverage of every partition a winner's posting list touches goes up by one
+    const int np = n_acc;
+    for (int e = tid; e < np * words; e += 1024) {
+        const int r = e / words, wd = e % words;
+        unsigned bits = res_bits[((size_t)slot_s[top[r]] * 2 + 1) * words + wd];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            atomicAdd(&coverage[wd * 32 + b], 1u);
+        }
+    }
+}
+
+// Cover every segment that holds a winner: take one off the live count of every word of the segments that are
+// covered now.  A block takes 64 postings at a time.  Wave 0 does the per-posting bookkeeping; the four waves
 // then gather the 64 segments' word ids into an LDS tile (64 window positions per pass, 16 loads per
 // thread in flight) and split the window positions between them with lane = posting: neighbouring
 // postings are the same window of near-identical genomes, so equal targets are merged across the
-// wave before the atomic (same-address atomics serialise in L2).  The last block records the
-// winner.
-// kNarrow: the candidate-list loop's variant.  The winner comes from best2[parity], the stamp from it1, and
-// block 0 records the winner on its own (nothing else in this kernel reads the fields it writes; k_select of
-// the next iteration does), so there is no last-block step.
-template <bool kNarrow>
+// wave before the atomic (same-address atomics serialise in L2).
+struct CoverShared {
+    int32_t tile[64 * 65];
+    uint32_t rows[64];   // partition-major row of each posting, ~0u: nothing to do
+    int any_live;
+};
+
+// the count updates of the 64 postings whose rows are in sh.rows (all threads of the block)
+__device__ __forceinline__ void cover_rows(CoverShared &sh, int per, const int32_t *kid_of_inst, int32_t *count)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q0 = 0; q0 < per; q0 += 64) {
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {   // 16 loads per thread in flight before the LDS stores
+            const int r = 4 * j + wave, q = q0 + lane;
+            const uint32_t row_r = sh.rows[r];
+            const bool ok = row_r != 0xffffffffu && q < per;
+            const int32_t x = kid_of_inst[ok ? (size_t)row_r * per + q : 0];
+            v[j] = ok ? x : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sh.tile[(4 * j + wave) * 65 + lane] = v[j];
+        __syncthreads();
+        const int nq = min(64, per - q0);
+        for (int qq = wave; qq < nq; qq += 4) {
+            const int32_t k2 = sh.tile[lane * 65 + qq];
+            // merge the common words of this window position (up to three rounds: the
+            // consensus word and its most frequent variants), the rest go one by one
+            unsigned long long mk = __ballot(k2 >= 0);
+            for (int round = 0; round < 3 && mk; ++round) {
+                const int l = __ffsll((long long)mk) - 1;
+                const int32_t kl = __builtin_amdgcn_readlane(k2, l);
+                const unsigned long long same = __ballot(k2 == kl);
+                if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
+                mk &= ~same;
+            }
+            if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
+        }
+        __syncthreads();
+    }
+}
+
+// live_part[p] = segments of partition p that are not covered yet (k_fast's bound): the newly covered ones of a
+// wave's 64 postings leave it, one atomic per distinct partition
+__device__ __forceinline__ void take_live(int32_t *live_part, bool live, int part, int lane)
+{
+    // (`live` here: newly covered AND marked, i.e. counted in live_part by k_mark)
+    unsigned long long ml = __ballot(live);
+    while (ml) {   // wave-uniform
+        const int l = __ffsll((long long)ml) - 1;
+        const int pl = __builtin_amdgcn_readlane(part, l);
+        const unsigned long long same = __ballot(live && part == pl);
+        if (lane == l) atomicSub(&live_part[pl], (int)__popcll(same));
+        ml &= ~same;
+    }
+}
+
+// The five-launch iteration's cover step: one winner (st->best), the partition coverage bumped once per
+// distinct partition of its posting list (main.rs:371-378, covered segments included) through a stamp per
+// partition; the last block records the winner.
 __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_off,
                                                const uint32_t *post, uint8_t *ignored,
                                                uint32_t *coverage, uint32_t *stamp, int P, int G,
                                                int per, const int32_t *kid_of_inst, int32_t *count,
                                                const uint64_t *ukeys, uint64_t *out_key,
-                                               uint32_t *out_freq, int parity)
+                                               uint32_t *out_freq, int32_t *live_part, const uint8_t *marked)
 {
-    __shared__ int32_t tile[64 * 65];
-    __shared__ uint32_t rows_s[64];   // partition-major row of each posting, ~0u: nothing to do
-    __shared__ int any_live;
-    if (st->stop || (kNarrow && st->need_rebuild)) return;
-    const uint32_t it1 = kNarrow ? st->it1 : (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
-    const unsigned long long best = kNarrow ? st->best2[parity] : st->best;
+    __shared__ CoverShared sh;
+    if (st->stop) return;
+    const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
+    const unsigned long long best = st->best;
     const uint32_t kid = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
-    if (kNarrow && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int mf = st->maxf, nw = st->n_win;
-        out_key[nw] = ukeys[kid];
-        out_freq[nw] = (uint32_t)mf;
-        st->winner = (int)kid;
-        st->n_win = nw + 1;
-        if (mf < st->min_freq) st->stop_next = 1;   // main.rs:387-390: stop after the push
-        st->maxf = 0;   // k_max_count starts from zero
-    }
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
@@ -734,9 +1678,10 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                 live = !ignored[row];
                 ignored[row] = 1;   // a segment appears once per posting list: no race
             }
-            rows_s[lane] = live ? row : 0xffffffffu;
+            sh.rows[lane] = live ? row : 0xffffffffu;
             const unsigned long long lives = __ballot(live);
-            if (lane == 0) any_live = lives != 0ull;
+            if (lane == 0) sh.any_live = lives != 0ull;
+            take_live(live_part, live && marked[row], part, lane);
             unsigned long long m = __ballot(part >= 0);
             while (m) {   // once per distinct partition of the wave
                 const int l = __ffsll((long long)m) - 1;
@@ -748,43 +1693,12 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
             if (rep) old_stamp = atomicExch(&stamp[part], it1);
         }
         __syncthreads();
-        if (any_live) {
-            for (int q0 = 0; q0 < per; q0 += 64) {
-                int32_t v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {   // 16 loads per thread in flight before the LDS stores
-                    const int r = 4 * j + wave, q = q0 + lane;
-                    const uint32_t row_r = rows_s[r];
-                    const bool ok = row_r != 0xffffffffu && q < per;
-                    const int32_t x = kid_of_inst[ok ? (size_t)row_r * per + q : 0];
-                    v[j] = ok ? x : -1;
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) tile[(4 * j + wave) * 65 + lane] = v[j];
-                __syncthreads();
-                const int nq = min(64, per - q0);
-                for (int qq = wave; qq < nq; qq += 4) {
-                    const int32_t k2 = tile[lane * 65 + qq];
-                    // merge the common words of this window position (up to three rounds: the
-                    // consensus word and its most frequent variants), the rest go one by one
-                    unsigned long long mk = __ballot(k2 >= 0);
-                    for (int round = 0; round < 3 && mk; ++round) {
-                        const int l = __ffsll((long long)mk) - 1;
-                        const int32_t kl = __builtin_amdgcn_readlane(k2, l);
-                        const unsigned long long same = __ballot(k2 == kl);
-                        if (lane == l) atomicSub(&count[kl], (int)__popcll(same));
-                        mk &= ~same;
-                    }
-                    if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
-                }
-                __syncthreads();
-            }
-        }
+        if (sh.any_live) cover_rows(sh, per, kid_of_inst, count);
         if (rep && old_stamp != it1) atomicAdd(&coverage[part], 1u);   // first posting of the partition this iteration
-        __syncthreads();   // rows_s / any_live are rewritten by the next group
+        __syncthreads();   // sh.rows / any_live are rewritten by the next group
     }
     __syncthreads();
-    if (!kNarrow && threadIdx.x == 0) {
+    if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
             const int mf = st->maxf;
@@ -797,6 +1711,52 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
             st->best = 0;
             st->ticket = 0;
         }
+    }
+}
+
+// The candidate-list iteration's cover step: all the winners k_prefix recorded, a 64-posting chunk of one of
+// them per work item.  The winners' LIVE segments lie in pairwise different partitions (that is what made them a
+// prefix), so the count updates of different winners never meet in a segment; a covered segment that two
+// posting lists share is marked twice, harmlessly.  (The partition coverage is k_prefix's.)
+__global__ void __launch_bounds__(256) k_cover_multi(const PickState *ps, const uint32_t *post_off,
+                                                     const uint32_t *post, uint8_t *ignored, int P, int G, int per,
+                                                     const int32_t *kid_of_inst, int32_t *count, int32_t *live_part,
+                                                     const uint8_t *marked)
+{
+    __shared__ CoverShared sh;
+    __shared__ uint32_t cum_s[kMaxPick + 1], kid_s[kMaxPick];
+    const unsigned np = ps->n_pick;
+    if (np == 0) return;
+    if (threadIdx.x <= np) cum_s[threadIdx.x] = ps->cum[threadIdx.x];
+    if (threadIdx.x < np) kid_s[threadIdx.x] = ps->kid[threadIdx.x];
+    __syncthreads();
+    const unsigned total = cum_s[np];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
+        unsigned j = 0;   // the winner this chunk belongs to (block-uniform)
+        while (j + 1 < np && cum_s[j + 1] <= item) ++j;
+        const uint32_t kid = kid_s[j];
+        const uint32_t base = post_off[kid] + (item - cum_s[j]) * 64u, e = post_off[kid + 1];
+        if (wave == 0) {
+            const uint32_t i = base + lane;
+            uint32_t row = 0;
+            int part = -1;
+            bool live = false;
+            if (i < e) {
+                const uint32_t seg = post[i];
+                part = (int)(seg % (uint32_t)P);
+                row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
+                live = !ignored[row];
+                ignored[row] = 1;
+            }
+            sh.rows[lane] = live ? row : 0xffffffffu;
+            const unsigned long long lives = __ballot(live);
+            if (lane == 0) sh.any_live = lives != 0ull;
+            take_live(live_part, live && marked[row], part, lane);
+        }
+        __syncthreads();
+        if (sh.any_live) cover_rows(sh, per, kid_of_inst, count);
+        __syncthreads();   // sh.rows / any_live are rewritten by the next item
     }
 }
 
@@ -872,7 +1832,7 @@ int KmerStage::ensure(int slot, size_t bytes, std::string &err)
 
 void KmerStage::release()
 {
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 19; ++s) {
         if (buf_[s]) (void)hipFree(buf_[s]);
         buf_[s] = nullptr;
         cap_[s] = 0;
@@ -938,18 +1898,24 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     const uint64_t sentinel = 1ull << (2 * k);
     int rc;
     // buffers: 0/1 keys, 2/3 vals, 4 head, 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
-    // 10 count+tied, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp
+    // 10 count+tied, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp, 16 the candidate-list loop's
+    // PickState + per-word results (key, id, two partition bitmaps)
     if ((rc = ensure(0, n_inst * 8, err)) || (rc = ensure(1, n_inst * 8, err)) ||
-        (rc = ensure(2, n_inst * 4, err)) || (rc = ensure(3, n_inst * 4, err)) ||
+        (rc = ensure(3, n_inst * 4, err)) ||
         (rc = ensure(4, n_inst * 4, err)) || (rc = ensure(5, n_inst * 4, err)) ||
         (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
         (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
         (rc = ensure(12, (size_t)P * 8, err)) ||
-        (rc = ensure(13, 128 + (size_t)opt.max_iterations * 12, err)))
+        (rc = ensure(13, 256 + (size_t)opt.max_iterations * 16, err)))
         return rc;
+    const size_t pwords = (size_t)((P + 31) / 32);
+    const size_t pick_bytes = (sizeof(PickState) + 255) & ~(size_t)255;
+    const size_t res_bytes = ((size_t)kEMax * (8 + 4 + 2 * 4 * pwords) + 255) & ~(size_t)255;
+    const size_t multi_bytes = ((size_t)kMaxMulti * sizeof(MultiInfo) + 255) & ~(size_t)255;
+    if ((rc = ensure(16, pick_bytes + res_bytes + multi_bytes + (size_t)kMaxMulti * 4, err))) return rc;
     uint64_t *key_a = (uint64_t *)buf_[0], *key_b = (uint64_t *)buf_[1];
-    uint32_t *val_a = (uint32_t *)buf_[2], *val_b = (uint32_t *)buf_[3];
+    uint32_t *val_b = (uint32_t *)buf_[3];
     uint32_t *head = (uint32_t *)buf_[4], *hscan = (uint32_t *)buf_[5];
     int32_t *kid_of_inst = (int32_t *)buf_[6];
     uint32_t *post = (uint32_t *)buf_[7], *post_off = (uint32_t *)buf_[8];
@@ -959,26 +1925,44 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     uint8_t *ignored = (uint8_t *)buf_[11];
     uint32_t *coverage = (uint32_t *)buf_[12], *stamp = coverage + P;
     Status *st = (Status *)buf_[13];
-    uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 128);
+    uint64_t *out_key = (uint64_t *)((char *)buf_[13] + 256);
     uint32_t *out_freq = (uint32_t *)(out_key + opt.max_iterations);
+    uint32_t *out_trace = out_freq + opt.max_iterations;   // per winner: how it was selected (diagnostics)
+    PickState *ps = (PickState *)buf_[16];
+    unsigned long long *res_key = (unsigned long long *)((char *)buf_[16] + pick_bytes);
+    uint32_t *res_kid = (uint32_t *)(res_key + kEMax);
+    unsigned *res_bits = (unsigned *)(res_kid + kEMax);
+    MultiInfo *multi = (MultiInfo *)((char *)buf_[16] + pick_bytes + res_bytes);
+    uint32_t *mcand = (uint32_t *)((char *)multi + multi_bytes);
 
-    // 1. extraction, 2. inverted index (the key type by the word length)
-    const int wins_per_block = std::max(1, 256 / per);
-    const int ext_grid = (n_seg + wins_per_block - 1) / wins_per_block;
-    const size_t ext_lds = sizeof(uint64_t) * wins_per_block * per + (size_t)wins_per_block * W;
+    // 1. extraction (from the packed alignment: byte rows are packed first), 2. inverted index (the key type by
+    //    the word length)
+    const uint64_t *d_packed = d_seqs.packed;
+    if (!d_packed) {
+        if ((rc = ensure(18, sizeof(uint64_t) * (size_t)n_seq * SeqView::row_words(seq_len), err))) return rc;
+        KM_TRY(launch_pack_rows(d_seqs.ascii, n_seq, seq_len, (uint64_t *)buf_[18], stream));
+        d_packed = (const uint64_t *)buf_[18];
+    }
+    const int ext_grid = std::min((n_seg + 3) / 4, 8192);   // one window per wave at a time
     if (per > 256) {
         err = "stage A: search window too wide for the extraction kernel";
         return MSSPE_ERR_ARG;
     }
     int M = 0;
+    uint16_t *word_part = nullptr;   // [M] partition of a word's first posting
+    uint8_t *word_multi = nullptr;   // [M] 1: the word has postings in several partitions
+    int32_t *live_part = nullptr;    // [P] live segments of the partition that hold a word of the current candidate list
+    uint32_t *cand_flag = nullptr;   // [M] the list (Status::epoch) a word was last on
+    uint8_t *marked = nullptr;       // [n_seg] the segment was counted in live_part
     auto build_index = [&](auto key_tag) -> int {
         using Key = decltype(key_tag);
         Key *ka = (Key *)key_a, *kb = (Key *)key_b;
-        hipLaunchKernelGGL(k_extract<Key>, dim3(ext_grid), dim3(256), ext_lds, stream, d_seqs, seq_len, n_seg,
-                           (int)P, opt.segment_size, opt.overlap_size, W, k, direction, per,
-                           wins_per_block, ka, val_a);
+        hipLaunchKernelGGL(k_extract<Key>, dim3(ext_grid), dim3(256), 0, stream, d_packed, seq_len, n_seg,
+                           (int)P, opt.segment_size, opt.overlap_size, W, k, direction, per, ka);
         KM_TRY(hipGetLastError());
-        // stable radix sort on the 2k+1 key bits keeps ascending segment order
+        // stable radix sort on the 2k+1 key bits keeps ascending segment order; the values (instance numbers) are
+        // not stored anywhere before the sort: a counting iterator supplies them
+        const rocprim::counting_iterator<uint32_t> val_a(0u);
         size_t tmp_bytes = 0, tmp2 = 0;
         KM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u,
                                          (unsigned)(2 * k + 1), stream));
@@ -997,8 +1981,17 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         M = (int)(last_head + last_scan);
         if (M == 0) return MSSPE_OK;
         // number of valid instances = first sentinel position: post_off[M]
+        const size_t wp_bytes = ((size_t)M * 3 + 15) & ~(size_t)15, lp_bytes = (4 * (size_t)P + 15) & ~(size_t)15;
+        if ((rc2 = ensure(17, wp_bytes + lp_bytes + 4 * (size_t)M + (size_t)n_seg, err))) return rc2;
+        word_part = (uint16_t *)buf_[17];
+        word_multi = (uint8_t *)(word_part + M);
+        live_part = (int32_t *)((char *)buf_[17] + wp_bytes);
+        cand_flag = (uint32_t *)((char *)buf_[17] + wp_bytes + lp_bytes);
+        marked = (uint8_t *)(cand_flag + M);
+        KM_TRY(hipMemsetAsync(live_part, 0, lp_bytes + 4 * (size_t)M + (size_t)n_seg, stream));   // epoch 0 = on no list; nothing marked
+        KM_TRY(hipMemsetAsync(word_multi, 0, (size_t)M, stream));
         hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, head, hscan, n_inst,
-                           sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys);
+                           sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
         // post_off[M] = number of non-sentinel instances (sentinels sort last)
         hipLaunchKernelGGL(k_tail<Key>, dim3(1), dim3(1), 0, stream, kb, n_inst, sentinel, post_off, M);
         return MSSPE_OK;
@@ -1020,37 +2013,58 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     h0.winner = -1;
     h0.max_iter = std::min(opt.max_iterations, capacity);
     h0.min_freq = opt.max_mismatch_segments;
+    h0.need_rebuild = 1;   // the candidate-list loop starts by making its list
     KM_TRY(hipMemcpyAsync(st, &h0, sizeof h0, hipMemcpyHostToDevice, stream));
+    KM_TRY(hipMemsetAsync(ps, 0, sizeof(PickState), stream));
+    KM_TRY(hipMemsetAsync(out_trace, 0, sizeof(uint32_t) * (size_t)opt.max_iterations, stream));
     KM_TRY(hipStreamSynchronize(stream));
     auto enqueue_iteration = [&](hipStream_t s_, int /*node*/) {
-        hipLaunchKernelGGL(k_max_count<false>, dim3(red_grid), dim3(256), 0, s_, count, M, st);
+        hipLaunchKernelGGL(k_max_count<false>, dim3(red_grid), dim3(256), 0, s_, count, M, st, 0, (int32_t *)nullptr, 0);
         hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
                            post_off, tied);
         hipLaunchKernelGGL(k_tie_scores, dim3(256), dim3(256), tie_lds, s_, tied, st, post_off, post,
                            ignored, coverage, (int)P, n_seq);
         hipLaunchKernelGGL(k_tie_long, dim3(64), dim3(1024), tie_lds / 4, s_, tied, M, st, post_off,
                            post, ignored, coverage, (int)P, n_seq);
-        hipLaunchKernelGGL(k_cover<false>, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, 0);
+        hipLaunchKernelGGL(k_cover, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
+                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, live_part, marked);
     };
-    // the candidate-list iteration (two launches); `tied` doubles as the candidate list
+    // the candidate-list iteration; `tied` doubles as the candidate list
     uint32_t *cand = tied;
-    const size_t sel_lds = 17 * sizeof(unsigned) * (size_t)((P + 31) / 32);
-    auto enqueue_narrow = [&](hipStream_t s_, int node) {
-        if (node == 0) {
-            // head of the batch: the maximum, theta and the candidate list (and the stop decision)
-            hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, s_, count, M, st);
-            hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, post_off,
-                               cand);
-        }
-        hipLaunchKernelGGL(k_select, dim3(kSelectGrid), dim3(1024), sel_lds, s_, st, count, cand, post_off, post,
-                           ignored, coverage, (int)P, n_seq, node & 1);
-        hipLaunchKernelGGL(k_cover<true>, dim3(256), dim3(256), 0, s_, st, post_off, post, ignored, coverage,
-                           stamp, (int)P, n_seq, per, kid_of_inst, count, ukeys, out_key, out_freq, node & 1);
+    const size_t sel_lds = 34 * sizeof(unsigned) * pwords;   // a pair of partition bitmaps for the block and for each wave
+    // the candidate-list loop's three pieces.  A batch (graph) holds iterations only; the host looks at the flags
+    // between batches and puts a list rebuild or one walking iteration in front of the next batch when asked to
+    // (the remaining iterations of a batch that asked are no-ops)
+    auto enqueue_rebuild = [&](hipStream_t s_) {
+        // the maximum, theta, the candidate list, the marked segments (and the stop decision)
+        hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, s_, count, M, st, 0, live_part, (int)P);
+        hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, post_off, cand,
+                           word_multi, mcand, cand_flag);
+        hipLaunchKernelGGL(k_mark, dim3(1024), dim3(256), 0, s_, st, kid_of_inst, ignored, cand_flag, n_seg, per, n_seq,
+                           marked, live_part);
     };
-    // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration:
-    // 29 -> 27 ms per direction at 10,000 genomes)
+    auto enqueue_general = [&](hipStream_t s_) {
+        // an iteration k_fast could not settle: posting walks for the words at the top of the order
+        hipLaunchKernelGGL(k_score, dim3(kSelectGrid), dim3(1024), sel_lds, s_, st, ps, count, cand, post_off, post,
+                           ignored, coverage, (int)P, n_seq, res_key, res_kid, res_bits);
+        hipLaunchKernelGGL(k_prefix, dim3(1), dim3(1024), 0, s_, st, ps, res_key, res_kid, res_bits, post_off, ukeys,
+                           coverage, out_key, out_freq, out_trace, (int)P);
+        hipLaunchKernelGGL(k_cover_multi, dim3(256), dim3(256), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
+                           kid_of_inst, count, live_part, marked);
+    };
+    auto enqueue_narrow = [&](hipStream_t s_, int /*node*/) {
+        // the few candidates with postings in several partitions are walked; everything else is read off the counts
+        hipLaunchKernelGGL(k_multi, dim3(kSelectGrid), dim3(1024), 0, s_, st, mcand, post_off, post, ignored, (int)P,
+                           n_seq, multi);
+        hipLaunchKernelGGL(k_fast, dim3(1), dim3(1024), 0, s_, st, ps, count, cand, word_part, word_multi, multi,
+                           live_part, coverage, post_off, ukeys, kid_of_inst, per, n_seq, out_key, out_freq, out_trace,
+                           (int)P);
+        hipLaunchKernelGGL(k_cover_multi, dim3(256), dim3(256), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
+                           kid_of_inst, count, live_part, marked);
+    };
+    // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration)
     constexpr int kBatch = 32;
+    constexpr int kBatchN = 8;    // candidate-list iterations per graph (an iteration selects up to 64 winners)
     GraphGuard gg[2];   // 0: five-launch iterations, 1: candidate-list iterations
     bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
     auto capture = [&](int which) -> bool {
@@ -1058,7 +2072,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         hipStream_t cs = nullptr;
         bool ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
         if (ok && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int b = 0; b < kBatch; ++b) which ? enqueue_narrow(cs, b) : enqueue_iteration(cs, b);
+            for (int b = 0; b < (which ? kBatchN : kBatch); ++b) which ? enqueue_narrow(cs, b) : enqueue_iteration(cs, b);
             ok = hipStreamEndCapture(cs, &gg[which].graph) == hipSuccess && gg[which].graph &&
                  hipGraphInstantiate(&gg[which].exec, gg[which].graph, nullptr, nullptr, 0) == hipSuccess;
         } else {
@@ -1072,14 +2086,16 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     Status h = h0;
     int wide_left = 0;   // five-launch batches still to run after a candidate list came out too long
     for (int batch = 0; !h.stop; ++batch) {
-        if (narrow_ok ? batch >= h0.max_iter + 2 : batch * kBatch >= h0.max_iter + 1) break;
+        if (narrow_ok ? batch >= 2 * h0.max_iter + 4 : batch * kBatch >= h0.max_iter + 1) break;
         const int which = narrow_ok && wide_left == 0 ? 1 : 0;
         if (wide_left) --wide_left;
+        if (which && h.need_rebuild == 1) enqueue_rebuild(stream);
+        if (which && h.want_general && h.need_rebuild != 1) enqueue_general(stream);
         if (use_graph && !gg[which].exec && !capture(which)) use_graph = false;
         if (use_graph) {
             KM_TRY(hipGraphLaunch(gg[which].exec, stream));
         } else {
-            for (int b = 0; b < kBatch; ++b) which ? enqueue_narrow(stream, b) : enqueue_iteration(stream, b);
+            for (int b = 0; b < (which ? kBatchN : kBatch); ++b) which ? enqueue_narrow(stream, b) : enqueue_iteration(stream, b);
         }
         KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
@@ -1087,10 +2103,14 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         if (which && h.too_many) wide_left = 4;
     }
     const int n_win = h.n_win;
+    loop_stats_[0] = h.it_fast;
+    loop_stats_[1] = h.it_general;
+    loop_stats_[2] = h.it_rebuild;
+    loop_stats_[3] = h.it_idle;
     if (narrow_ok && !h.stop_next && n_win >= capacity && n_win < opt.max_iterations) {
         // the candidate-list loop stops at max_iter without looking at the words: is anything left?
         KM_TRY(hipMemsetAsync((char *)st + offsetof(Status, stop), 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, stream, count, M, st);
+        hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, stream, count, M, st, 1, (int32_t *)nullptr, 0);
         KM_TRY(hipGetLastError());
         KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
@@ -1104,6 +2124,8 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         std::vector<uint64_t> hk((size_t)n_win);
         KM_TRY(hipMemcpyAsync(hk.data(), out_key, sizeof(uint64_t) * n_win, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipMemcpyAsync(freq_out, out_freq, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
+        trace_.resize((size_t)n_win);
+        KM_TRY(hipMemcpyAsync(trace_.data(), out_trace, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
         for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
     }

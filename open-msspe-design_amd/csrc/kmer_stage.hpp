@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/msspe_hip.h"
 
@@ -45,12 +46,20 @@ public:
     void set_use_graph(bool on) { use_graph_ = on; }
     // false: every iteration of the greedy loop scans all the words (the five-launch iteration)
     void set_narrow_loop(bool on) { narrow_loop_ = on; }
+    // the last run's candidate-list loop: iterations that recorded winners without a posting walk / with one,
+    // iterations that rebuilt the list, idle iterations at the end of the last batch
+    const int *loop_stats() const { return loop_stats_; }
+    // per winner of the last run: iteration << 8 | how it was selected (1 a partition's leader, 2 a several-partition
+    // word, 3 the same with a re-computed key, 4 after posting walks, 0 the all-words loop)
+    const std::vector<uint32_t> &trace() const { return trace_; }
 
 private:
-    void *buf_[16] = {};
-    size_t cap_[16] = {};
+    void *buf_[19] = {};
+    size_t cap_[19] = {};
     bool use_graph_ = true;
     bool narrow_loop_ = true;
+    int loop_stats_[4] = {};
+    std::vector<uint32_t> trace_;
     int ensure(int slot, size_t bytes, std::string &err);
 };
 

@@ -13,7 +13,7 @@ STATUS = {0: "MSSPE_OK", 1: "MSSPE_ERR_ARG", 2: "MSSPE_ERR_K", 3: "MSSPE_ERR_TAB
 # every symbol include/msspe_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "msspe_chem_ntthal_defaults", "msspe_chem_primer3_defaults", "msspe_create", "msspe_destroy",
-    "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_get_info", "msspe_set_stream", "msspe_reset_stream",
+    "msspe_last_error", "msspe_version", "msspe_set_option", "msspe_get_info", "msspe_kmer_trace", "msspe_set_stream", "msspe_reset_stream",
     "msspe_synchronize",
     "msspe_pack_oligos", "msspe_unpack_oligo", "msspe_cross_dimer_dev", "msspe_cross_dimer",
     "msspe_cross_dimer_edges_dev", "msspe_cross_dimer_edges",
@@ -96,6 +96,7 @@ def load_library() -> C.CDLL:
     L.msspe_set_stream.argtypes = [vp, vp]
     L.msspe_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.msspe_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_longlong)]
+    L.msspe_kmer_trace.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.msspe_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.msspe_group_destroy.argtypes = [vp]
     L.msspe_group_destroy.restype = None
@@ -243,6 +244,15 @@ class Engine:
         self._check(self.L.msspe_get_info(self.ptr, key.encode(), C.byref(v)))
         return int(v.value)
 
+    def kmer_trace(self) -> np.ndarray:
+        """Per winner of the last kmer_candidates call: (iteration, how it was selected) -- msspe_kmer_trace."""
+        n = C.c_int(0)
+        self._check(self.L.msspe_kmer_trace(self.ptr, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        self._check(self.L.msspe_kmer_trace(self.ptr, out.ctypes.data, int(out.size), C.byref(n)))
+        out = out[:n.value]
+        return np.stack([out >> 8, out & 0xff], axis=1)
+
     def reset_stream(self):
         self._check(self.L.msspe_reset_stream(self.ptr))
 
@@ -383,6 +393,34 @@ class Engine:
             self._check(self.L.msspe_kmer_candidates_dev(
                 self.ptr, C.c_void_p(device_ptr), n_seq, seq_len, C.byref(opt), direction,
                 words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
+        m = n_out.value
+        return [unpack_oligo(w, opt.kmer_size) for w in words[:m]], freqs[:m].copy()
+
+    def put_rows_packed(self, seqs: np.ndarray) -> int:
+        """Upload an alignment (uint8 (n_seq, L)) in its compact device form (2-bit bases + validity bit, packed on
+        the device behind the copy: msspe_device_put_rows_packed).  Returns the device address; free it with
+        device_free()."""
+        a = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n_seq, seq_len = a.shape
+        ptrs = (C.c_char_p * n_seq)(*[C.cast(a[i].ctypes.data, C.c_char_p) for i in range(n_seq)])
+        lens = (C.c_size_t * n_seq)(*([seq_len] * n_seq))
+        dev = C.c_void_p()
+        self._check(self.L.msspe_device_put_rows_packed(self.ptr, ptrs, lens, n_seq, seq_len, C.byref(dev)))
+        return int(dev.value)
+
+    def device_free(self, device_ptr: int) -> None:
+        self._check(self.L.msspe_device_free(self.ptr, C.c_void_p(device_ptr)))
+
+    def kmer_candidates_packed(self, d_packed: int, n_seq: int, seq_len: int, opt: KmerOpt, direction: int,
+                               capacity: int | None = None):
+        """Stage A on a packed alignment resident on the device (put_rows_packed).  Returns (words, freqs)."""
+        cap = max(1, opt.max_iterations if capacity is None else capacity)
+        words = np.zeros(cap, dtype=np.uint64)
+        freqs = np.zeros(cap, dtype=np.uint32)
+        n_out = C.c_int(0)
+        self._check(self.L.msspe_kmer_candidates_packed_dev(
+            self.ptr, C.c_void_p(d_packed), n_seq, seq_len, C.byref(opt), direction,
+            words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
         m = n_out.value
         return [unpack_oligo(w, opt.kmer_size) for w in words[:m]], freqs[:m].copy()
 

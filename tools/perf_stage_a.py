@@ -23,14 +23,19 @@ eng = m.Engine(0)
 for kv in os.environ.get("MSSPE_PROBE_OPTIONS", "").split(","):
     if kv:
         eng.set_option(*kv.split("="))
-d = torch.from_numpy(g).cuda()
+packed = os.environ.get("MSSPE_PROBE_ASCII", "") == ""
+d = eng.put_rows_packed(g) if packed else torch.from_numpy(g).cuda()
 opt = m.KmerOpt(500, 250, 50, 13, 1000, max(1, min(10, -(-rows // 50))))
 for direction in (0, 1):
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.time()
-        words, freqs = eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=rows, seq_len=length)
+        if packed:
+            words, freqs = eng.kmer_candidates_packed(d, rows, length, opt, direction)
+        else:
+            words, freqs = eng.kmer_candidates(None, opt, direction, device_ptr=d.data_ptr(), n_seq=rows, seq_len=length)
         dt = time.time() - t0
     segs = rows * ((length - 500) // 250 + 1)
+    its = [eng.info("stage_a_" + x) for x in ("fast_iterations", "general_iterations", "rebuilds", "idle_iterations")]
     print(f"dir {direction}: {len(words)} winners, top freq {freqs[:3].tolist()}, {dt*1e3:.1f} ms, "
-          f"{segs/dt/1e6:.2f} M segments/s", flush=True)
+          f"{segs/dt/1e6:.2f} M segments/s; iterations fast/general/rebuilds/idle {its}", flush=True)
