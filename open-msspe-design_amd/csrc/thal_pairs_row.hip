@@ -53,7 +53,6 @@ constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not avai
 constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
 constexpr int kRowGBase = FastTables::kTSc;      // first compact-table entry kept in LDS
 constexpr int kRowGCount = FastTables::kCount - kRowGBase;
-constexpr int kNoY = 1 << 28;                    // table entries at or above kNoY / 2 carry this offset: no cell-side term
 // The running minimum of a scan is ONE v_min_f64 on the pair (candidate value : slot word): every vector
 // instruction of this loop issues at the same rate, f64 or not, and a minimum of two 64-bit
 // patterns with the value on top is compare + two selects in one.  For that the patterns must be positive
@@ -61,14 +60,16 @@ constexpr int kNoY = 1 << 28;                    // table entries at or above kN
 // candidates (|value| < kReach) and the void ones (kRowU instead of kBig in this table and in the cell-side
 // terms) into [2^20, 0x7fefffff] as high words.
 constexpr int kRowD = 350000000;
-constexpr int kRowU = 850000000;                 // "not available" in T: still void (>= kValid) after any reachable predecessor
+constexpr int kRowU = 700000000;                 // "not available" in T and in the cell-side terms: a candidate that holds one is
+                                                 // beyond anything a cell can take (every cell value is a reachable one, < kReach)
+constexpr int kRowInit = kRowD + IntTables::kReach + 50000000;   // the scan's starting minimum: above every valid candidate, below every void one
 static_assert(kRowD - IntTables::kReach >= (1 << 20), "smallest candidate must be a normal double's high word");
 // (a predecessor's value is always a reachable one: pairs_row_tables_ok() admits only chemistries whose end and
 //  stacked-pair terms are all finite, and a cell takes its value from those or from a non-void candidate)
-static_assert((long long)IntTables::kReach + kRowU + IntTables::kReach + kRowD <= 0x7fefffffLL,
-              "largest candidate (valid loop + void cell side + reachable predecessor) must stay a finite double");
-static_assert(kRowU - IntTables::kReach >= IntTables::kValid, "a void entry stays void");
-static_assert((long long)kRowU + kNoY + kRowD < 0x7fffffffLL, "table entries are int32");
+static_assert((long long)kRowU + kRowU + IntTables::kReach + kRowD <= 0x7fefffffLL,
+              "largest candidate (void loop + void cell side + reachable predecessor) must stay a finite double");
+static_assert(kRowU + kRowD - IntTables::kReach > kRowInit && kRowInit - kRowD > IntTables::kReach,
+              "a candidate that holds a void term stays above the starting minimum, which no cell can take");
 // No address clamp: a predecessor that is not up-left of the cell makes the 17-bit address field wrap to at least
 // kRowWrapMin; with the table placed so that those addresses lie beyond the block's LDS allocation the read
 // returns 0 (gfx950: every ds_read at or beyond the allocation, rounded up to 1,280 bytes, reads 0;
@@ -76,9 +77,10 @@ static_assert((long long)kRowU + kNoY + kRowD < 0x7fffffffLL, "table entries are
 // fails it, and a context with option row_oob = 0, runs the general integer kernel instead), and 0 is made
 // to mean "not available": every table entry carries - kRowZero and every slot value + kRowZero.  That saves
 // the unsigned min that clamped the address in every visit.
-constexpr int kRowZero = kRowU + kNoY + kRowD;   // the stored pattern of "not available" before the shift: now 0
+constexpr int kRowZero = kRowU + kRowD;          // the stored pattern of "not available" before the shift: now 0
 static_assert((long long)IntTables::kReach + kRowZero < 0x7fffffffLL, "slot values + kRowZero are int32");
-static_assert(-(long long)IntTables::kReach + kRowD - kRowZero > -0x7fffffffLL, "table entries - kRowZero are int32");
+static_assert(-(long long)IntTables::kReach - kRowU + kRowD - kRowZero > -0x7fffffffLL,
+              "table entries (a folded-in void cell-side term included) - kRowZero are int32");
 constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
 // slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
 //             bits 14..0   h + kHBias
@@ -213,29 +215,36 @@ __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, con
 // All slots below `upto` as predecessors of the cell, kC at a time; chunks at or above near_from (the
 // row above the cell) also catch the cell (i-1, j-1).  The chunks are unrolled with compile-time register
 // numbers and left through a wave-uniform branch.
+// run / far: one bit per chunk (set by the caller once per ROW of the DP: which chunks hold slots of the rows above,
+// which of them lie entirely in rows i-2 and above).  Two scalar words instead of two comparisons per chunk whose
+// results the compiler would keep alive, as lane masks, across the whole cell.
 template <int NS, int PC = 0>
-__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int near_from, const char *T,
+__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, unsigned run, unsigned far, int near_from, const char *T,
                                               const RCell &c, RowBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC * kC < NS) {
-        if (PC * kC < upto) {   // wave-uniform
+        if ((run >> PC) & 1u) {   // wave-uniform
             ChunkLoad cur;
             chunk_issue<NS, PC>(MSSPE_TAB_ARGS, T, c, cur);
-            if (PC * kC + kC <= near_from) {   // wave-uniform: slots of rows i-2 and above
+            if ((far >> PC) & 1u) {   // wave-uniform: slots of rows i-2 and above
                 asm volatile("" ::"n"(PC));   // keeps the chunks from being merged into selects
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS;
-                    const int cand = cur.t[e] + y + Gp;   // unavailable: kRowU + ..., never below the minimum <= kValid (all + kRowD)
+                    // every entry of these rows (r >= 2) takes the cell-side term: where the loop has none of its own
+                    // (l2 <= 1) the table holds the loop term MINUS it (build_row_table).  Unavailable: kRowU + ...
+                    const int cand = cur.t[e] + c.yTS + Gp;
                     take_min(best, cand, Wp);
                 }
             } else {
                 asm volatile("" ::"n"(PC + 64));
+                int rem = near_from - PC * kC;   // slots of this chunk that still belong to row i-2
+                asm volatile("" : "+s"(rem));    // (computed here, per use: hoisted out of the cell loop it costs a register per slot)
 #pragma unroll
                 for (int e = 0; e < kC; ++e) {
                     const int Gp = slot_of<NS>(Ga, Gb, Gc, PC * kC + e), Wp = slot_of<NS>(Wa, Wb, Wc, PC * kC + e);
-                    const int y = cur.t[e] >= kNoY / 2 + kRowD - kRowZero ? -kNoY : c.yTS;
+                    // the row above the cell (r = 1) takes no cell-side term; slots of row i-2 at the head of this chunk do
+                    const int y = c.yTS & (e < rem ? -1 : 0);   // a wave-uniform mask (one s_cselect_b32)
                     const int cand = cur.t[e] + y + Gp;
                     take_min(best, cand, Wp);
                     const bool isstk = cur.idx[e] == (unsigned)c.idxStk;   // the cell (i-1, j-1)
@@ -244,7 +253,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, int upto, int ne
                     m.stHave |= __builtin_amdgcn_ballot_w64(isstk);
                 }
             }
-            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, upto, near_from, T, c, best, stk, m);
+            scan_fill_row<NS, PC + 1>(MSSPE_TAB_ARGS, run, far, near_from, T, c, best, stk, m);
         }
     }
 }
@@ -285,6 +294,9 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
       // The cells of the last row are nobody's predecessors: they are computed and may be picked, but take no
       // slot (a pair needs cells - cells of the last row slots: three or four more pairs in a hundred fit)
       const bool stored = im1 < q.len - 1;   // wave-uniform
+      // chunks that hold slots below row_start / that lie entirely below the first slot of row i-1 (scalars)
+      const unsigned run_chunks = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << ((row_start + kC - 1) / kC)) - 1u));
+      const unsigned far_chunks = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << (start_im1 / kC)) - 1u));
       unsigned mrem = active ? spaced_mask(q.s2, 3 - a_row, q.lenmask) : 0u;
       for (int c_ = 0; c_ < w_row; ++c_, slot_ += stored ? 1 : 0) {
         const int slot = __builtin_amdgcn_readfirstlane(slot_);
@@ -300,14 +312,18 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         // ---- all earlier slots as predecessors
         RowBest rb;
         IBest stk;
-        rb.GW = __hiloint2double(IntTables::kValid + kRowD, 0);
+        rb.GW = __hiloint2double(kRowInit, 0);
         rb.G2 = 0x7fffffff;
         stk.G = stk.W = 0;
         ScanMasks sm;
         sm.tie = sm.stHave = 0ull;
         // predecessors: every slot of the rows above; row i-1 (where the cell (i-1, j-1) lives) through
         // the code that catches it
-        scan_fill_row<NS>(MSSPE_TAB_ARGS, row_start, start_im1, (const char *)sh.T, rc, rb, stk, sm);
+        {
+            unsigned run = run_chunks, far = far_chunks;
+            asm volatile("" : "+s"(run), "+s"(far));   // the per-chunk bit tests stay where they are used
+            scan_fill_row<NS>(MSSPE_TAB_ARGS, run, far, start_im1, (const char *)sh.T, rc, rb, stk, sm);
+        }
         const bool tie = rb.G2 == best_g(rb);   // two loop candidates share the minimum
         RBest best;
         best.G = best_g(rb) - kRowD;
@@ -654,12 +670,26 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
 //   bulges          column a_p | a_c << 2 (the general table holds both closing pairs)
 //   l2 == 1         the base between predecessor and cell on oligo 2 IS n2: 1 x 1 loops get their
 //                   cell-side mismatch, interior loops their cell-side terminal mismatch
-//   l2 >= 2, r >= 2 pred side only; the lane adds yts[i][m2].  Every other entry carries + kNoY.
-// r == 0 (same row), ii < 0, the stacked pair and loops the chemistry has no entry for: kBig (+ kNoY).
+//   l2 >= 2, r >= 2 pred side only; the lane adds yts[i][m2], m2 = the base left of the cell on oligo 2.
+// The lane adds that term to EVERY entry of the rows r >= 2 (one add, no select per visit), so the entries of those
+// rows that must not get it hold the loop term minus it: their m2 is known here -- l2 == 1: m2 is n2; l2 == 0: the
+// cell sits right of the predecessor, whose base on oligo 2 is the complement of oligo 1's at ii.  The row above the
+// cell (r == 1) takes no cell-side term at all.
+// r == 0 (same row), ii < 0, the stacked pair and loops the chemistry has no entry for: not available.
 __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a, unsigned s1)
 {
     const int32_t *Tg = a.it->T;
     const int32_t *Hg = a.f.ft->H;
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
+        const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
+        {
+            const int y = sh.g[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
+            sh.yts[threadIdx.x] = y >= IntTables::kValid ? kRowU : y;   // void stays void, and in range (kRowD)
+        }
+        sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < kRowTEntries; e += kRowThreads) {
         const int l2 = e / kRowA, rem = e - l2 * kRowA;
         const int n2 = 3 - (rem & 3), ir = rem >> 2, i = ir / 14, r = ir - i * 14;
@@ -691,22 +721,19 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
             }
             if (v >= IntTables::kValid) hv = 0;
         }
-        if (v >= IntTables::kValid) v = kRowU;
-        sh.T[e] = (needs_y ? v : v + kNoY) + kRowD - kRowZero;   // "not available" is 0
+        if (v >= IntTables::kValid) {
+            v = kRowU;
+        } else if (!needs_y && r >= 2) {
+            // the lane will add yts[i][m2] to this entry although the loop has no such term: take it out here
+            const int m2 = l2 == 1 ? n2 : 3 - (int)((s1 >> (2 * ii)) & 3u);
+            v -= sh.yts[(i << 2) | m2];
+        }
+        sh.T[e] = v + kRowD - kRowZero;   // "not available" is 0
         sh.TH[e] = (short)(((hv / 10) << 1) | (needs_y ? 1 : 0));
     }
     if (threadIdx.x < 4) {
-        sh.T[kRowTEntries + threadIdx.x] = kRowU + kNoY + kRowD - kRowZero;
+        sh.T[kRowTEntries + threadIdx.x] = 0;
         sh.TH[kRowTEntries + threadIdx.x] = 0;
-    }
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x >> 2, m2 = threadIdx.x & 3;
-        const int a_c = (int)((s1 >> (2 * i)) & 3u), m1 = i > 0 ? (int)((s1 >> (2 * i - 2)) & 3u) : 0;
-        {
-            const int y = sh.g[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
-            sh.yts[threadIdx.x] = y >= IntTables::kValid ? kRowU : y;   // void stays void, and in range (kRowD)
-        }
-        sh.ytsh[threadIdx.x] = sh.h[FastTables::kTSc - kRowGBase + (((3 - a_c) * 4 + m2) * 4 + m1)];
     }
 }
 
