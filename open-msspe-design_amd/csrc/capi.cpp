@@ -45,6 +45,7 @@ struct ChemEntry {
 };
 
 constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
+constexpr int kHairpinLaneFrom = 8192;       // oligos per call from which HAIRPIN_TH runs one lane per oligo (msspe_oligo_stats_dev)
 constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows with the call up to kListCapMax): one launch can never overrun it
 constexpr long kListCapMax = 1L << 30;       // 8 GB per list (two of them, 6 % of the card's memory): the stages behind the first
                                              // run every eight launches of 2^27 pairs, so that a list cannot be overrun even if
@@ -1100,9 +1101,13 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         h.wsS = ctx->wsS;
         h.wsH = ctx->wsH;
         h.ws_lanes = kGenericLanes;
-        // one wave per oligo with the DP planes in LDS (thal_hairpin_wave.hip); the one-lane kernel over a
-        // global workspace stays as the reference implementation behind option "force_generic"
-        if (ctx->opt.force_generic || k > 32) HIP_TRY(ctx, launch_hairpin_generic(h, ctx->stream));
+        // What the reference's loop produces (<= 2,000 oligos per call, main.rs:344): one wave per oligo with the DP
+        // planes in LDS (thal_hairpin_wave.hip), whose latency is a single oligo's.  A pool large enough to give
+        // every SIMD several full waves: one LANE per oligo over a global workspace laid out [cell][lane]
+        // (kernels_generic.hip) -- measured 1,048,576 13-mers: 7.8 ms against 61.7 ms (the serial exterior-loop pass
+        // and traceback run in 64 lanes instead of one); 65,536: 0.51 against 4.05; the crossing is near 8,192.
+        // (Option "force_generic" takes the one-lane kernel always.)
+        if (ctx->opt.force_generic || k > 32 || n >= kHairpinLaneFrom) HIP_TRY(ctx, launch_hairpin_generic(h, ctx->stream));
         else HIP_TRY(ctx, launch_hairpin_wave(h, ctx->n_cu, ctx->stream));
     }
     return MSSPE_OK;

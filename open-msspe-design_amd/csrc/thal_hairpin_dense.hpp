@@ -488,7 +488,7 @@ struct HairpinCtx {
     }
 
     // thal.c drawHairpin()'s totals from the filled planes (terminal pass, traceback, Tm)
-    __device__ void finish(ThalOut &o)
+    __device__ void finish(ThalOut &o, bool tm_only = false)
     {
         const int n = s.len;
         terminal_bp();
@@ -498,6 +498,21 @@ struct HairpinCtx {
         o.dS = o.dH = o.dG = 0.0;
         o.n_pairs = 0;
         if (!isfinite(mh_)) return;
+        if (tm_only) {
+            // The caller only wants max(0, t) (libprimer3 oligo_hairpin()).  t = mh / (ms + x salt) - 273.15 with
+            // x = N / 2 - 1, N the paired positions the traceback would count (-1 <= x <= len / 2): where the
+            // denominator keeps its sign over that range, t is monotone in x, so if it is negative at both ends
+            // it is negative for whatever the traceback finds -- the result is 0 without walking.
+            const double d0 = ms_ + ((-1) * c.salt), d1 = ms_ + ((n / 2) * c.salt);
+            if ((d0 < 0.0) == (d1 < 0.0) && d0 != 0.0 && d1 != 0.0) {
+                const double t0 = (mh_ / d0) - kAbsZero, t1 = (mh_ / d1) - kAbsZero;
+                if (t0 < 0.0 && t1 < 0.0) {
+                    o.none = 0;
+                    o.t = -1.0;   // any negative value: the caller reports 0
+                    return;
+                }
+            }
+        }
         const uint64_t bp = traceback();
         const int N = __popcll(bp & ((1ull << (n - 1)) - 1));   // drawHairpin: i = 1 .. len-1
         o.n_pairs = __popcll(bp) / 2;

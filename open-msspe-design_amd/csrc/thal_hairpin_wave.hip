@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) k_hairpin_wave(HairpinArgs a)
         }
         if (lane == 0) {
             ThalOut o;
-            ctx.finish(o);
+            ctx.finish(o, true);   // only max(0, t) leaves this kernel
             a.out_t[w] = (o.none || o.t < 0.0) ? 0.0 : o.t;   // libprimer3 oligo_hairpin(): max(0, t)
         }
         __syncthreads();   // the planes are reused by the next oligo

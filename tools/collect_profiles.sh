@@ -8,12 +8,19 @@ OUT=gpurun_out/profiles_raw
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o bench -- python3 bench.py --steps 2 --warmup 1 > $OUT/bench_stdout.log 2>&1 || exit 1
 echo "bench done"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc1 -- python3 tools/perf_probe.py 16384 > $OUT/pmc1.log 2>&1 || exit 1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- python3 tools/perf_probe.py 16384 > $OUT/pmc2.log 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/perf_probe.py 16384 > $OUT/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/perf_probe.py 16384 > $OUT/pmc_write.log 2>&1 || exit 1
+# the counters on the BENCH ITSELF: one step of the 65,536-primer pool (4.29e9 checks, 33 launches of the first stage)
+PMCRUN="python3 bench.py --steps 1 --warmup 0 --no-stage-a --no-stage-b --no-cpu-baseline"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc1 -- $PMCRUN > $OUT/pmc1.log 2>&1 || exit 1
+echo "pmc1 done"
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $PMCRUN > $OUT/pmc2.log 2>&1 || exit 1
+echo "pmc2 done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $PMCRUN > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $PMCRUN > $OUT/pmc_write.log 2>&1 || exit 1
 echo "pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_a_stats -o stagea -- python3 tools/perf_stage_a.py 10000 30000 > $OUT/stage_a_stdout.log 2>&1 || exit 1
 echo "stage a done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_b_stats -o stageb -- python3 tools/perf_stage_b.py 1048576 > $OUT/stage_b_stdout.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_b2k_stats -o stageb2k -- python3 tools/perf_stage_b.py 2000 > $OUT/stage_b2k_stdout.log 2>&1 || exit 1
+echo "stage b done"
 timeout -k 10 120 tools/valu_peak > $OUT/valu_peak.jsonl 2>&1; echo "valu_peak done"
 echo done

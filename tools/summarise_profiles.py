@@ -14,7 +14,7 @@ RAW = ROOT / "gpurun_out" / "profiles_raw"
 OUT = ROOT / "profiles"
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 kLaunchChecks = 134217728.0            # 2^27 pairs: one full launch
-kProbeChecks = 3.0 * 16384.0 * 16384.0   # tools/perf_probe.py 16384 = three passes over the pool
+kProbeChecks = 65536.0 * 65536.0       # the counter passes run the bench itself: one step of the 65,536-primer pool
 KERNEL = "k_pairs_row"
 KERNEL_MATCH = "k_pairs_row<"   # the row-specialised first stage (thal_pairs_row.hip)
 # the commit whose kernels were measured: the last one that touched the kernel sources (pass it as argv[2] when
@@ -43,6 +43,10 @@ def pmc(sub):
 
 shutil.copy(RAW / "bench_stats" / "bench_kernel_stats.csv", OUT / f"{ROUND}_bench_kernel_stats.csv")
 shutil.copy(RAW / "stage_a_stats" / "stagea_kernel_stats.csv", OUT / f"{ROUND}_stage_a_kernel_stats.csv")
+for sub, name in (("stage_b_stats", "stageb"), ("stage_b2k_stats", "stageb2k")):
+    src = RAW / sub / f"{name}_kernel_stats.csv"
+    if src.exists():
+        shutil.copy(src, OUT / f"{ROUND}_{'stage_b_1m' if name == 'stageb' else 'stage_b_2000'}_kernel_stats.csv")
 line = [l for l in open(RAW / "bench_stdout.log") if l.startswith('{"metric"')][-1]
 (OUT / f"{ROUND}_bench_line.json").write_text(line)
 
@@ -56,7 +60,7 @@ clock_ghz = c2["GRBM_GUI_ACTIVE"] / 8.0 / (ms2 * 1e-3) / 1e9
 simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
 wave_slots = 1024.0 * 3.0   # 768-thread blocks: three waves per SIMD
 with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
-    f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 tools/perf_probe.py 16384 ; kernel {KERNEL},\n"
+    f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 bench.py --steps 1 --warmup 0 (the bench's own 65,536-primer pool); kernel {KERNEL},\n"
             f"# mean per dispatch (2^27 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
             f"# GRBM_GUI_ACTIVE sums the 8 XCDs (/8 = {c2['GRBM_GUI_ACTIVE']/8e6:.1f} M cycles in {ms2:.2f} ms = {clock_ghz:.2f} GHz)\n")
     for name, (c, ms, n) in (("pass 1", (c1, ms1, n1)), ("pass 2", (c2, ms2, n2)), ("FETCH_SIZE [KB]", (cf, msf, nf)),
@@ -77,13 +81,13 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "round": int(ROUND[1:]), "commit": COMMIT,
-    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/perf_probe.py 16384",
+    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-stage-a --no-stage-b --no-cpu-baseline",
     "launches_sampled": nf,
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
     "note": "scaled to one full launch of 2^27 ordered pairs; traffic = the 64-byte atomics that set conflict bits "
-            "(0.5 % of pairs), the list of pairs handed to the later stages (about 7 %, 8 B each), the per-pair register "
+            "(0.5 % of pairs), the list of pairs handed to the later stages (about 2 %, 8 B each), the per-pair register "
             "spills of the three-wave shape (none inside the cell loop) and the per-row table builds; algorithmic bytes "
             "per launch are about 21 MB"}, indent=1))
 (OUT / "pmc_latest.json").write_text(json.dumps({
