@@ -8,7 +8,8 @@
 //   2. an inverted index word -> ascending segment list is built (radix sort of 2k-bit keys);
 //   3. the greedy loop picks, up to max_iterations times, the word present in most uncovered
 //      segments (ties: partition_tie_score in f32, then the lexicographically smallest word),
-//      covers its segments and decrements the live counts of every word they hold.
+//      covers its segments and decrements the live counts of every word they hold -- here a whole run of
+//      such picks per iteration, exactly (k_fast / k_score + k_prefix below).
 // The reference rebuilds a string-keyed HashMap over all live segments on every iteration
 // (O(iterations x instances)); here the counts are maintained incrementally, which is exact
 // because a segment is covered at most once.

@@ -22,18 +22,19 @@
 //     K = 772 jj + 4 ii + n2  (n2 = the base of oligo 2 right of the predecessor), so that ONE
 //     subtraction from a per-cell constant yields the table index:
 //         C - K = 772 (j - 1 - jj) + 4 (14 i + (i - ii)) + (3 - n2)
-//     A predecessor right of the cell (j - 1 - jj < 0) makes the 17-bit field wrap and an unsigned min
-//     clamps it onto a "not available" entry: no validity test, no loop classification, no column
-//     fix-up.  772 = 4 (mod 64): the 64 lanes of a wave sit on nearly the same rows (same slot number),
+//     A predecessor right of the cell (j - 1 - jj < 0) makes the 17-bit field wrap onto an address beyond the
+//     block's LDS allocation, which reads 0 = "not available" (kRowZero below): no validity test, no loop
+//     classification, no column fix-up.  772 = 4 (mod 64): the 64 lanes of a wave sit on nearly the same rows (same slot number),
 //     what differs between them is l2 and n2, and with this stride the 48 (l2, n2) combinations fall
 //     into 48 different LDS banks (a power-of-two layout puts them all into one: measured 16-way
 //     conflicts, the kernel then gains 4 % instead of 30 %).
-//     What is left of the classification is one select: the cell-side mismatch term of an interior
-//     loop with l2 >= 2 needs the base left of the cell on oligo 2, which only the lane knows; the
-//     table marks the entries that must NOT get it by a 2^28 offset.
-//   * far visit (predecessor known to lie three or more rows up):  sub, lshr, min, [ds_read], cmp,
-//     cndmask, add3, cmp, cmp, cndmask, min = 2 full-rate + 8 half-rate instructions (16 before);
-//     near visit: + cmp, 2 x cndmask that catch the cell (i-1, j-1) for maxTM.
+//     Nothing is left of the classification: the cell-side mismatch term of an interior loop with l2 >= 2 needs the
+//     base left of the cell on oligo 2, which only the lane knows, so the lane adds it to EVERY entry of the rows
+//     two or more above the cell, and the entries that must not get it hold the loop term minus it (their m2 is
+//     known when the table is built: build_row_table).
+//   * far visit (predecessor known to lie two or more rows up):  sub, lshr, [ds_read], add3, med3, mov, min_f64
+//     = 3 full-rate + 3 half-rate instructions (general kernel: 16); near visit (the row above the cell):
+//     + cmp, 2 x cndmask that catch the cell (i-1, j-1) for maxTM.
 //
 // Ties, maxTM, the terminal pick, the traceback by pointer and the f64 replay of the optimal path are
 // those of thal_pairs_int.hip; a pair this kernel does not answer goes to the same hand-over list.
