@@ -1717,8 +1717,9 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
 
 // The candidate-list iteration's cover step: all the winners k_prefix recorded, a 64-posting chunk of one of
 // them per work item.  The winners' LIVE segments lie in pairwise different partitions (that is what made them a
-// prefix), so the count updates of different winners never meet in a segment; a covered segment that two
-// posting lists share is marked twice, harmlessly.  (The partition coverage is k_prefix's.)
+// prefix), so the count updates of different winners never meet in a segment -- with one exception, a
+// several-partition word accepted with a re-computed key, which is why a segment is claimed with an atomic before
+// it is covered (below).  (The partition coverage is k_fast's / k_prefix's.)
 __global__ void __launch_bounds__(256) k_cover_multi(const PickState *ps, const uint32_t *post_off,
                                                      const uint32_t *post, uint8_t *ignored, int P, int G, int per,
                                                      const int32_t *kid_of_inst, int32_t *count, int32_t *live_part,
@@ -1747,8 +1748,13 @@ __global__ void __launch_bounds__(256) k_cover_multi(const PickState *ps, const 
                 const uint32_t seg = post[i];
                 part = (int)(seg % (uint32_t)P);
                 row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
-                live = !ignored[row];
-                ignored[row] = 1;
+                // Two winners of one iteration may share a segment that is still live: a several-partition word
+                // accepted with a re-computed key lists the segments of its minor partition that the partition's
+                // leader takes as well.  The reference covers it once (the second winner finds it ignored), so the
+                // segment is CLAIMED: one atomic on the flag's 32-bit word, whoever sets the byte covers it.
+                const unsigned sh8 = 8u * (row & 3u);
+                const unsigned old = atomicOr(reinterpret_cast<unsigned *>(ignored + (row & ~3u)), 1u << sh8);
+                live = ((old >> sh8) & 0xffu) == 0u;
             }
             sh.rows[lane] = live ? row : 0xffffffffu;
             const unsigned long long lives = __ballot(live);
@@ -1906,7 +1912,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         (rc = ensure(4, n_inst * 4, err)) || (rc = ensure(5, n_inst * 4, err)) ||
         (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
-        (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, (size_t)n_seg, err)) ||
+        (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, ((size_t)n_seg + 7) & ~(size_t)3, err)) ||
         (rc = ensure(12, (size_t)P * 8, err)) ||
         (rc = ensure(13, 256 + (size_t)opt.max_iterations * 16, err)))
         return rc;

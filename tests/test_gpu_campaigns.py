@@ -22,6 +22,8 @@ def run_tool(monkeypatch, name, *args):
     ("random_campaign.py", (77, 3)),            # case 0 of this seed: a skewed pool with waves without any cell
     ("random_campaign.py", (5, 2, 17, 26)),
     ("random_campaign_stage_a.py", (11, 16)),
+    ("random_campaign_stage_a_big.py", (5, 14)),       # the multi-winner loop's regime: hundreds of rows, duplicated blocks, clades
+    ("random_campaign_stage_a_big.py", (5, 40, 35)),   # case 35: two winners of one iteration share a live segment (claimed once)
     ("random_campaign_stage_b.py", (3, 12)),
     ("random_campaign_blocks.py", (8, 14)),
     ("random_campaign_cli.py", (21, 8)),

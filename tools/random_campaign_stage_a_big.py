@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign for stage A's multi-winner loop (development aid, GPU): larger alignments in the
+regime the fast path is made for -- hundreds to thousands of near-identical rows, default windows -- with the things
+that stress it: duplicated column blocks (words with many postings in SEVERAL partitions), clades (several
+ancestors), gaps and N runs.  The candidate-list loop against the all-words loop (one winner per iteration: round 1's
+loop, itself checked against the oracle by the other campaign), both directions, whole winner sequences with their
+frequencies; the oracle too where the case is small.  usage: random_campaign_stage_a_big.py [seed] [cases]"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "open-msspe-design_amd"))
+sys.path.insert(0, str(ROOT / "oracle"))
+import numpy as np
+import msspe_amd as m
+import pyoracle as o
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1    # evaluate this case alone (the others still draw their random numbers)
+eng = m.Engine(0)
+bad = 0
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+for it in range(cases):
+    rows = int(rng.integers(150, 2500))
+    L = int(rng.integers(2000, 12000))
+    k = int(rng.choice([9, 11, 13, 13, 13, 15]))
+    seg, stride, win = (500, 250, 50) if it % 3 else (int(rng.integers(200, 600)), int(rng.integers(60, 300)), int(rng.integers(k + 5, 60)))
+    iters = int(rng.choice([1000, 1000, 300, 40]))
+    mm = int(rng.choice([1, 2, 5, 10]))
+    mu = float(rng.choice([0.004, 0.02, 0.02, 0.06]))
+    clades = int(rng.choice([1, 1, 2, 4]))
+    anc = [rng.integers(0, 4, L) for _ in range(clades)]
+    if it % 2:   # duplicated blocks: the same words in two or three partitions
+        for a in anc:
+            for _ in range(int(rng.integers(1, 4))):
+                w = int(rng.integers(30, 400))
+                src, dst = int(rng.integers(0, L - w)), int(rng.integers(0, L - w))
+                a[dst:dst + w] = a[src:src + w]
+    arr = np.empty((rows, L), dtype=np.uint8)
+    for r in range(rows):
+        row = anc[r % clades].copy()
+        mut = rng.random(L) < mu
+        row[mut] = rng.integers(0, 4, int(mut.sum()))
+        a = ACGT[row].copy()
+        if it % 4 == 3:
+            for _ in range(int(rng.integers(0, 3))):
+                p0 = int(rng.integers(0, L)); a[p0:p0 + int(rng.integers(1, 60))] = ord("-")
+            if rng.random() < 0.2:
+                p0 = int(rng.integers(0, L)); a[p0:p0 + int(rng.integers(1, 150))] = ord("N")
+        arr[r] = a
+    opt = m.KmerOpt(seg, stride, win, k, iters, mm)
+    if only >= 0 and it != only:
+        continue
+    ok = True
+    info = []
+    for d in (0, 1):
+        eng.set_option("stage_a_candidates", 0)
+        w0, f0 = eng.kmer_candidates(arr, opt, d)
+        eng.set_option("stage_a_candidates", 1)
+        w1, f1 = eng.kmer_candidates(arr, opt, d)
+        tr = eng.kmer_trace()
+        same = list(w0) == list(w1) and f0.tolist() == f1.tolist()
+        if not same and only >= 0:
+            n = min(len(w0), len(w1))
+            b = next((i for i in range(n) if w0[i] != w1[i] or f0[i] != f1[i]), n)
+            print(f"dir {d}: {len(w0)} vs {len(w1)} winners, first difference at {b}")
+            for i in range(max(0, b - 6), min(n, b + 4)):
+                print("  ", i, w0[i], int(f0[i]), "|", w1[i], int(f1[i]), tr[i].tolist())
+            # where the words around the difference live: partition -> segments holding them (all of them, covered or not)
+            P = (L - seg) // stride + 1
+            comp = str.maketrans("ACGT", "TGCA")
+            for word in sorted({w0[b], w1[b], w0[b - 1]}):
+                look = word if d == 0 else word[::-1].translate(comp)
+                cnt = {}
+                for r in range(rows):
+                    row = bytes(arr[r]).decode()
+                    for part in range(P):
+                        c0 = part * stride + (seg - win if d else 0)
+                        if look in row[c0:c0 + win]:
+                            cnt[part] = cnt.get(part, 0) + 1
+                print("   word", word, "partitions", cnt)
+        if (same and rows * L <= 3_000_000) or only >= 0:
+            want = o.Segments([bytes(r).decode() for r in arr], seg, stride, win, k).candidates(d, iters, mm)
+            if only >= 0:
+                print("oracle == all-words loop:", list(zip(w0, f0.tolist())) == want, " oracle == candidate-list loop:",
+                      list(zip(w1, f1.tolist())) == want)
+            same = same and list(zip(w1, f1.tolist())) == want
+        ok = ok and same
+        hist = np.bincount(tr[:, 1], minlength=5).tolist() if len(tr) else [0] * 5
+        info.append(f"{len(w1)} winners in {int(tr[:, 0].max()) if len(tr) else 0} it. {hist}")
+    print(it, f"rows {rows} L {L} k {k} seg {seg}/{stride}/{win} iters {iters} mm {mm} mu {mu} clades {clades}", "dup" if it % 2 else "",
+          "|", " ; ".join(info), ok, flush=True)
+    bad += not ok
+print("BAD", bad)
+sys.exit(1 if bad else 0)
