@@ -118,35 +118,30 @@ __global__ void __launch_bounds__(256) k_pack_rows(const uint8_t *ascii, int n_r
 // [2q, 2q+1] -- and its k validity bits the same way.  The emitted key is the word's lexicographic code (first
 // base in the most significant bits): for the head window the 2-bit groups of x reversed (bit reverse + swap
 // within pairs), for the tail window, whose k-mers are stored reverse-complemented (main.rs:213-224), simply the
-// complement of x -- reversing the order and reading LSB-first instead of MSB-first cancel.  First occurrence per
-// window (itertools::unique, main.rs:168): the wave's valid lanes enter their x into a small open-addressing table
-// in LDS (compare-and-swap on the key, minimum on the position) and keep their word iff they hold the minimum.
+// complement of x -- reversing the order and reading LSB-first instead of MSB-first cancel.
+// First occurrence per window (itertools::unique, main.rs:168), without memory: the lanes that share an 8-bit
+// hash of x are found with eight ballots (a lane's mask = the AND over the hash bits of the ballot or its
+// complement); a lane then compares its x with the x of the earlier lanes of its mask only, fetched by shuffle --
+// almost always none (38 positions in 256 buckets), so the loop runs once or twice per window.  Windows wider than
+// 64 positions take several passes of 64; a later pass also compares with the earlier passes' words, kept in LDS.
 // Only the keys are written, 4 (k <= 15) or 8 bytes per window position in one contiguous run per wave; the
 // instance numbers the sort carries along come from a counting iterator.
-constexpr int kExtTab = 512;   // table slots per wave (a window has at most 256 positions: KmerStage::run)
-
 template <class Key>
 __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t seq_len, int n_seg, int P, int seg_size,
                                                  int stride, int W, int k, int direction, int per, Key *key_out)
 {
-    __shared__ unsigned long long tab_x[4][kExtTab];
-    __shared__ int tab_p[4][kExtTab];
+    __shared__ unsigned long long prev_x[4][256];   // the valid words of the window's earlier passes (per > 64 only)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
     const size_t bw = (seq_len + 31) / 32, vw = (seq_len + 63) / 64, rw = bw + vw;
     const unsigned long long xmask = (1ull << (2 * k)) - 1ull, vmask = (1ull << k) - 1ull;
+    const unsigned long long below = (1ull << lane) - 1ull;
     const Key sentinel = (Key)(1ull << (2 * k));
-    for (int e = lane; e < kExtTab; e += 64) {
-        tab_x[wv][e] = ~0ull;
-        tab_p[wv][e] = 0x7fffffff;
-    }
-    __builtin_amdgcn_wave_barrier();
     for (int seg = wave; seg < n_seg; seg += n_waves) {   // wave-uniform
-        int hs[4] = {-1, -1, -1, -1};   // the lane's table slots of this window (one per pass of 64 positions)
         const int rec = seg / P, part = seg - rec * P;
         const uint64_t *row = packed + (size_t)rec * rw;
         const size_t c0 = (size_t)part * (size_t)stride + (size_t)(direction ? seg_size - W : 0);
-        for (int p0 = 0; p0 < per; p0 += 64) {   // (windows wider than 64 + k - 1 take several passes; dedup spans them)
+        for (int p0 = 0; p0 < per; p0 += 64) {   // wave-uniform
             const int p = p0 + lane;
             const bool in = p < per;
             const size_t col = c0 + (size_t)(in ? p : 0);
@@ -157,20 +152,28 @@ __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t 
             const unsigned long long x = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & xmask;
             const unsigned long long vb = ((vlo >> vs) | (vs ? vhi << (64 - vs) : 0ull)) & vmask;
             const bool ok = in && vb == vmask;
-            // first occurrence in the window
-            int h = 0;
-            if (ok) {
-                h = (int)((x * 0x9e3779b97f4a7c15ull) >> 55);   // 9 bits
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&tab_x[wv][h], ~0ull, x);
-                    if (old == ~0ull || old == x) break;
-                    h = (h + 1) & (kExtTab - 1);
-                }
-                atomicMin(&tab_p[wv][h], p);
+            // lanes with my hash (valid ones only)
+            const unsigned hsh = (unsigned)((x * 0x9e3779b97f4a7c15ull) >> 56);
+            unsigned long long same = __ballot(ok);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long bm = __ballot((hsh >> bit) & 1u);
+                same &= ((hsh >> bit) & 1u) ? bm : ~bm;
             }
-            __builtin_amdgcn_wave_barrier();
-            bool keep = false;
-            if (ok) keep = tab_p[wv][h] == p;
+            unsigned long long cand = ok ? (same & below) : 0ull;   // earlier lanes that may hold my word
+            bool dup = false;
+            while (__ballot(cand != 0ull)) {   // wave-uniform trip count: the longest chain of equal hashes (mostly 0)
+                const int src = cand ? __ffsll((long long)cand) - 1 : lane;
+                const unsigned xl = (unsigned)__shfl((int)(unsigned)x, src), xh = (unsigned)__shfl((int)(unsigned)(x >> 32), src);
+                dup = dup || (cand && (((unsigned long long)xh << 32) | xl) == x);
+                cand &= cand - 1ull;
+            }
+            if (p0 > 0 && ok && !dup)   // (wide windows) the earlier passes' words
+                for (int q = 0; q < p0 && !dup; ++q) dup = prev_x[wv][q] == x;
+            if (per > 64) {
+                prev_x[wv][p & 255] = ok ? x : ~0ull;
+                __builtin_amdgcn_wave_barrier();
+            }
             unsigned long long word;
             if (direction) {
                 word = ~x & xmask;
@@ -178,18 +181,8 @@ __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t 
                 unsigned long long r = __brevll(x) >> (64 - 2 * k);
                 word = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
             }
-            if (in) key_out[(size_t)seg * per + p] = keep ? (Key)word : sentinel;
-            hs[p0 >> 6] = ok ? h : -1;
+            if (in) key_out[(size_t)seg * per + p] = (ok && !dup) ? (Key)word : sentinel;
         }
-        __builtin_amdgcn_wave_barrier();
-        // the table is the next window's: every entry that was used goes back to empty
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 64 < per && hs[q] >= 0) {
-                tab_x[wv][hs[q]] = ~0ull;
-                tab_p[wv][hs[q]] = 0x7fffffff;
-            }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -376,6 +369,15 @@ __global__ void __launch_bounds__(256) k_collect_cand(const int32_t *count, int 
             if (at < kMaxMulti) mcand[at] = (uint32_t)i;
         }
     }
+}
+
+// The first list of a run needs no marking pass: every segment is live, every segment counts (the bound that comes
+// of it is loose, but the first leaders cover most of their partitions: it does not bind).
+__global__ void __launch_bounds__(256) k_live_all(const Status *st, int32_t *live_part, int P, int G)
+{
+    if (st->stop || st->need_rebuild != 2) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) live_part[p] = G;
 }
 
 // Behind a new candidate list: which live segments hold a word of the list (marked), and how many of them each
@@ -1839,6 +1841,8 @@ int KmerStage::ensure(int slot, size_t bytes, std::string &err)
 
 void KmerStage::release()
 {
+    if (pinned_) (void)hipHostFree(pinned_);
+    pinned_ = nullptr;
     for (int s = 0; s < 19; ++s) {
         if (buf_[s]) (void)hipFree(buf_[s]);
         buf_[s] = nullptr;
@@ -1995,7 +1999,8 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         live_part = (int32_t *)((char *)buf_[17] + wp_bytes);
         cand_flag = (uint32_t *)((char *)buf_[17] + wp_bytes + lp_bytes);
         marked = (uint8_t *)(cand_flag + M);
-        KM_TRY(hipMemsetAsync(live_part, 0, lp_bytes + 4 * (size_t)M + (size_t)n_seg, stream));   // epoch 0 = on no list; nothing marked
+        KM_TRY(hipMemsetAsync(live_part, 0, lp_bytes + 4 * (size_t)M, stream));   // epoch 0 = on no list
+        KM_TRY(hipMemsetAsync(marked, 1, (size_t)n_seg, stream));                  // the first list counts every segment (k_live_all)
         KM_TRY(hipMemsetAsync(word_multi, 0, (size_t)M, stream));
         hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, head, hscan, n_inst,
                            sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
@@ -2042,13 +2047,19 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     // the candidate-list loop's three pieces.  A batch (graph) holds iterations only; the host looks at the flags
     // between batches and puts a list rebuild or one walking iteration in front of the next batch when asked to
     // (the remaining iterations of a batch that asked are no-ops)
+    bool first_list = true;
     auto enqueue_rebuild = [&](hipStream_t s_) {
         // the maximum, theta, the candidate list, the marked segments (and the stop decision)
         hipLaunchKernelGGL(k_max_count<true>, dim3(red_grid), dim3(256), 0, s_, count, M, st, 0, live_part, (int)P);
         hipLaunchKernelGGL(k_collect_cand, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st, post_off, cand,
                            word_multi, mcand, cand_flag);
-        hipLaunchKernelGGL(k_mark, dim3(1024), dim3(256), 0, s_, st, kid_of_inst, ignored, cand_flag, n_seg, per, n_seq,
-                           marked, live_part);
+        if (first_list) {   // nothing is covered yet: every segment counts (marked was set to ones with the other state)
+            hipLaunchKernelGGL(k_live_all, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s_, st, live_part, (int)P, n_seq);
+            first_list = false;
+        } else {
+            hipLaunchKernelGGL(k_mark, dim3(1024), dim3(256), 0, s_, st, kid_of_inst, ignored, cand_flag, n_seg, per,
+                               n_seq, marked, live_part);
+        }
     };
     auto enqueue_general = [&](hipStream_t s_) {
         // an iteration k_fast could not settle: posting walks for the words at the top of the order
@@ -2090,6 +2101,8 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         return ok;
     };
     const bool narrow_ok = narrow_loop_ && P <= kNarrowMaxP;
+    if (!pinned_) KM_TRY(hipHostMalloc(&pinned_, 256, hipHostMallocDefault));
+    Status *h_pin = (Status *)pinned_;
     Status h = h0;
     int wide_left = 0;   // five-launch batches still to run after a candidate list came out too long
     for (int batch = 0; !h.stop; ++batch) {
@@ -2105,8 +2118,9 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
             for (int b = 0; b < (which ? kBatchN : kBatch); ++b) which ? enqueue_narrow(stream, b) : enqueue_iteration(stream, b);
         }
         KM_TRY(hipGetLastError());
-        KM_TRY(hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipMemcpyAsync(h_pin, st, sizeof h, hipMemcpyDeviceToHost, stream));   // pinned: no staging copy per batch
         KM_TRY(hipStreamSynchronize(stream));
+        h = *h_pin;
         if (which && h.too_many) wide_left = 4;
     }
     const int n_win = h.n_win;

@@ -56,6 +56,7 @@ public:
 private:
     void *buf_[19] = {};
     size_t cap_[19] = {};
+    void *pinned_ = nullptr;   // the loop state's host copy (pinned: read back once per batch)
     bool use_graph_ = true;
     bool narrow_loop_ = true;
     int loop_stats_[4] = {};
