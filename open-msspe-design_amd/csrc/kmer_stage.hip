@@ -882,6 +882,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
                                                uint32_t *out_freq, uint32_t *out_trace, int P)
 {
     __shared__ unsigned long long lead[kFastMaxP];   // per partition: count << 32 | ~word id of its one-partition leader
+    __shared__ int second[kFastMaxP];                // ... and the highest count among its other one-partition candidates
     __shared__ unsigned long long lkey[kFastEnt];    // entries: count << 32 | score bits
     __shared__ uint32_t lkid[kFastEnt];
     __shared__ unsigned short lwho[kFastEnt];        // partition of a leader, or 0x8000 | index of a several-partition candidate
@@ -942,6 +943,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     }
     for (int e = tid; e < P; e += 1024) {
         lead[e] = 0ull;
+        second[e] = 0;
         ub[e] = -1;
         who[e] = kByMulti;
         tcount[e] = 0;
@@ -970,6 +972,16 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         if (tid == 0) st->need_rebuild = 1;
         return;
     }
+    // every partition's runner-up: once the leader is covered nothing that lives in the partition alone can have more than
+    // the runner-up has now (counts only fall), however many live segments the partition keeps -- the bound that still
+    // works late in the loop, when a leader covers a small part of what its partition has left
+    for (unsigned i = (unsigned)tid; i < n_cand; i += 1024) {
+        const uint32_t kid = cand[i] & ~kCandLong;
+        if (word_multi[kid]) continue;
+        const int p = word_part[kid];
+        if (kid != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull)) atomicMax(&second[p], count[kid]);
+    }
+    __syncthreads();
     // the entries: leaders with a count of at least theta (nothing below it may be accepted from this list) ...
     for (int p0 = 0; p0 < P; p0 += 1024) {
         const int p = p0 + tid;
@@ -1207,11 +1219,13 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
                 }
             } else {
                 const int p = lwho[w.ent];
-                ub[p] = live_part[p] - f;
+                ub[p] = live_part[p] - f;   // live segments p keeps (what a several-partition word's postings there are measured against)
                 who[p] = kid;
                 tcount[p] = 1;
                 cov_add[p] += 1;
-                bound = max(bound, ub[p]);
+                // what a word living in p alone can still have: no more than that, and no more than p's runner-up had
+                // (a word that is not on the list has less than theta)
+                bound = max(bound, min(ub[p], max(second[p], theta - 1)));
                 bump[nb++] = (unsigned short)p;
             }
         }

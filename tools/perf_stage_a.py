@@ -37,5 +37,11 @@ for direction in (0, 1):
         dt = time.time() - t0
     segs = rows * ((length - 500) // 250 + 1)
     its = [eng.info("stage_a_" + x) for x in ("fast_iterations", "general_iterations", "rebuilds", "idle_iterations")]
+    tr = eng.kmer_trace()
+    per_it = np.bincount(tr[:, 0]) if len(tr) else np.zeros(1, int)
+    kinds = np.bincount(tr[:, 1], minlength=5).tolist() if len(tr) else []
+    ends = [int(tr[np.flatnonzero(tr[:, 0] == i)[-1], 1]) for i in range(1, len(per_it)) if per_it[i]]
+    print("   winners per iteration:", per_it[1:].tolist())
+    print("   selected as [all-words, leader, several-partition, re-keyed, walked]:", kinds, " kind of each iteration's last winner:", np.bincount(ends, minlength=5).tolist())
     print(f"dir {direction}: {len(words)} winners, top freq {freqs[:3].tolist()}, {dt*1e3:.1f} ms, "
           f"{segs/dt/1e6:.2f} M segments/s; iterations fast/general/rebuilds/idle {its}", flush=True)
