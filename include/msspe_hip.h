@@ -77,7 +77,7 @@ const char *msspe_version(void);
  * --ntthal / --primer3 paths, od-msspe/src/config.rs:142-147).  Unknown key / bad value: MSSPE_ERR_ARG.
  *   "pair_kernel"    "auto" | "f64" (f64 register-table kernel first) | "int" (general integer kernel first)
  *   "force_generic"  "0" | "1"    dense one-lane-per-pair kernels only
- *   "split_min_k"    "2".."99"    shortest oligo that goes to the split-table kernel (15)
+ *   "split_min_k"    "2".."99"    shortest oligo that goes to the split-table kernel (16; 14- and 15-mers run the row-specialised first stage)
  *   "wave_kernel"    "0" | "1"    one-wave-per-pair f64 kernel in the chain (1)
  *   "list_cap_log2"  "0" | "20".."30"   fixed hand-over list size (0: sized by the call)
  *   "split_lanes"    "0" | "2" | "4" | "8"

@@ -61,7 +61,7 @@ constexpr size_t kGenericLanes = 1u << 16;   // lanes of the generic kernels' wo
 struct EngineOptions {
     int pair_kernel = 0;      // 0 auto | 1 f64 register-table kernel first | 2 general integer kernel first
     bool force_generic = false;
-    int split_min_k = 15;     // measured on 8,192 primers: k = 14 register tables 516 vs 250 M checks/s, k = 15 198 vs 202, k = 16 41 vs 165
+    int split_min_k = 16;     // 14- and 15-mers: the row-specialised first stage (round 3); 16 and up: the split-table kernel
     bool wave_kernel = true;
     int list_cap_log2 = 0;    // 0: sized by the call; 20..30: fixed (forces flushes mid-screen)
     int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
@@ -771,7 +771,8 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
                 a.col1 = col0 + (int)q_end;
                 HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, nullptr, nullptr, ctx->stream));
             } else if (split) HIP_TRY(ctx, launch_pairs_split(a, ce->d_st, ctx->d_reasons, ctx->opt.split_lanes, ctx->stream));
-            else if (int_stage && ce->row_ok && ctx->lds_reads_zero && ctx->opt.row_oob && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2)
+            else if (int_stage && ce->row_ok && k <= pairs_row_max_k() && ctx->opt.pair_kernel != 2 &&
+                     (k > pairs_row_oob_max_k() || (ctx->lds_reads_zero && ctx->opt.row_oob)))
                 HIP_TRY(ctx, launch_pairs_row(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else if (int_stage) HIP_TRY(ctx, launch_pairs_int(a, ce->d_it, ctx->d_reasons, ctx->n_cu, ctx->stream));
             else HIP_TRY(ctx, launch_pairs_fast(a, ctx->stream));

@@ -124,6 +124,7 @@ hipError_t launch_pairs_int(const PairKernelArgs &a, const IntTables *it, unsign
 hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
                             hipStream_t stream);
 int pairs_row_max_k();
+int pairs_row_oob_max_k();   // oligos up to here run the instance that reads LDS beyond its allocation (pairs_row_lds_reads_zero)
 bool pairs_row_tables_ok(const IntTables &it);   // host: may this chemistry run the row kernel?
 hipError_t pairs_row_lds_reads_zero(hipStream_t stream, int n_cu, bool *ok);   // does this device read 0 beyond a block's LDS allocation?
 // List mode of the integer stage: retries the pairs of in_list that carry no "needs f64" mark (bit

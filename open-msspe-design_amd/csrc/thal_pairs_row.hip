@@ -45,25 +45,33 @@ namespace msspe {
 
 namespace {
 
-constexpr int kRowK = 13;                        // longest oligo of this kernel
-constexpr int kRowThreads = 768, kRowSlots = 52;   // three waves per SIMD; 52 stored cells per pair
-constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. 11
-constexpr int kRowA = 772;                       // stride of l2: 4 * 14 * 13 = 728 entries used, = 4 (mod 64)
-constexpr int kRowTEntries = kRowL2 * kRowA;
-constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
-constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
-constexpr int kRowGBase = FastTables::kTSc;      // first compact-table entry kept in LDS
-constexpr int kRowGCount = FastTables::kCount - kRowGBase;
+// One class per (longest oligo, block shape): 13 bases with 768 threads and 52 stored cells (three waves per SIMD, the
+// table read without an address clamp), 15 bases with 512 threads and 64 stored cells (two waves per SIMD, clamped
+// addresses).  Everything below is the same code; the constants follow from the four parameters.
+template <int ROWK, int ROWT, int ROWS, bool ROWOOB>
+struct RowKernel {
+static constexpr int kRowK = ROWK;                      // longest oligo of this instance
+static constexpr int kRowThreads = ROWT, kRowSlots = ROWS;   // 13 bases: 768 threads (three waves per SIMD), 52 stored cells per pair
+static constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. k - 2
+static constexpr int kRowR = kRowK + 1;                 // digits of the row index: 14 i + (i - ii) at 13 bases
+// stride of l2: 4 * kRowR * kRowK entries used, rounded up to = 4 (mod 64) (13 bases: 728 -> 772; 15: 960 -> 964)
+static constexpr int kRowA = (4 * kRowR * kRowK + 59) / 64 * 64 + 4;
+static_assert(kRowA % 64 == 4 && kRowA >= 4 * kRowR * kRowK, "48 (l2, n2) combinations in 48 different LDS banks");
+static constexpr int kRowTEntries = kRowL2 * kRowA;
+static constexpr int kRowTBytes = kRowTEntries * 4;     // byte offset of the "not available" entry behind the table
+static constexpr int kHBias = 16384;                    // h = H / 10 is kept as h + kHBias in 15 bits
+static constexpr int kRowGBase = FastTables::kTSc;      // first compact-table entry kept in LDS
+static constexpr int kRowGCount = FastTables::kCount - kRowGBase;
 // The running minimum of a scan is ONE v_min_f64 on the pair (candidate value : slot word): every vector
 // instruction of this loop issues at the same rate, f64 or not, and a minimum of two 64-bit
 // patterns with the value on top is compare + two selects in one.  For that the patterns must be positive
 // normal doubles ordered like the values: every table entry carries + kRowD, which puts the reachable
 // candidates (|value| < kReach) and the void ones (kRowU instead of kBig in this table and in the cell-side
 // terms) into [2^20, 0x7fefffff] as high words.
-constexpr int kRowD = 350000000;
-constexpr int kRowU = 700000000;                 // "not available" in T and in the cell-side terms: a candidate that holds one is
+static constexpr int kRowD = 350000000;
+static constexpr int kRowU = 700000000;                 // "not available" in T and in the cell-side terms: a candidate that holds one is
                                                  // beyond anything a cell can take (every cell value is a reachable one, < kReach)
-constexpr int kRowInit = kRowD + IntTables::kReach + 50000000;   // the scan's starting minimum: above every valid candidate, below every void one
+static constexpr int kRowInit = kRowD + IntTables::kReach + 50000000;   // the scan's starting minimum: above every valid candidate, below every void one
 static_assert(kRowD - IntTables::kReach >= (1 << 20), "smallest candidate must be a normal double's high word");
 // (a predecessor's value is always a reachable one: pairs_row_tables_ok() admits only chemistries whose end and
 //  stacked-pair terms are all finite, and a cell takes its value from those or from a non-void candidate)
@@ -78,27 +86,28 @@ static_assert(kRowU + kRowD - IntTables::kReach > kRowInit && kRowInit - kRowD >
 // fails it, and a context with option row_oob = 0, runs the general integer kernel instead), and 0 is made
 // to mean "not available": every table entry carries - kRowZero and every slot value + kRowZero.  That saves
 // the unsigned min that clamped the address in every visit.
-constexpr int kRowZero = kRowU + kRowD;          // the stored pattern of "not available" before the shift: now 0
+static constexpr int kRowZero = kRowU + kRowD;          // the stored pattern of "not available" before the shift: now 0
 static_assert((long long)IntTables::kReach + kRowZero < 0x7fffffffLL, "slot values + kRowZero are int32");
 static_assert(-(long long)IntTables::kReach - kRowU + kRowD - kRowZero > -0x7fffffffLL,
               "table entries (a folded-in void cell-side term included) - kRowZero are int32");
-constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
+static constexpr int kSegGroups = 256;                  // column groups (of 64) per work item
 // slot word:  bits 31..17  K = 772 jj + 4 ii + n2     (bits 15, 16 zero: the byte offset is K << 2)
 //             bits 14..0   h + kHBias
 // an empty slot: K one beyond the largest real one (12 * 772 + 4 * 12 + 3), i.e. beyond every cell's minuend, so
 // that the difference is negative for every cell (and as large as possible after the wrap, see kRowWrapMin)
-constexpr int kEmptyRowK = (kRowK - 1) * kRowA + 4 * (kRowK - 1) + 3 + 1;
-constexpr int kEmptyRowW = (kEmptyRowK << 17) | kHBias;
+static constexpr int kEmptyRowK = (kRowK - 1) * kRowA + 4 * (kRowK - 1) + 3 + 1;
+static constexpr int kEmptyRowW = (kEmptyRowK << 17) | kHBias;
 // smallest table address (bytes) of a predecessor that is not up-left of the cell: either the minuend is the
 // smallest possible (column 1, row 0: K = 3) and the word the empty one, or the cell is in column 0, whose
 // minuend wraps to 2^15 - 769 + 60 i
-constexpr int kRowWrapMin = 4 * ((1 << 15) - 769 - kEmptyRowK) < (1 << 17) - 4 * (kEmptyRowK - 3)
-                                ? 4 * ((1 << 15) - 769 - kEmptyRowK) : (1 << 17) - 4 * (kEmptyRowK - 3);
+static constexpr int kRowWrapMin = 4 * ((1 << 15) - (kRowA - 3) - kEmptyRowK) < (1 << 17) - 4 * (kEmptyRowK - 3)
+                                ? 4 * ((1 << 15) - (kRowA - 3) - kEmptyRowK) : (1 << 17) - 4 * (kEmptyRowK - 3);
+static_assert(kEmptyRowK < (1 << 15), "K is a 15-bit field");
 
 // Order matters.  LDS instructions take a 16-bit immediate offset, so what is addressed as "lane + constant" or
 // "table + index" lives in the first 64 KB and needs no address arithmetic; and T sits so far
 // back that its wrapped addresses fall off the end of the allocation (static_asserts below the struct).
-constexpr int kPredLo = 24;   // rows of the predecessor bytes in front of T (the row number is a scalar: no cost)
+static constexpr int kPredLo = 24;   // rows of the predecessor bytes in front of T (the row number is a scalar: no cost)
 struct SharedRow {
     // per-lane state that is touched once per cell (registers are the scarce resource: 104 of a lane's
     // 168 hold the table, and what does not fit goes to scratch memory, i.e. to HBM latency)
@@ -125,43 +134,53 @@ struct SharedRow {
     }
 };
 static_assert(offsetof(SharedRow, T) <= 65532, "T is addressed with an immediate offset");
-static_assert(offsetof(SharedRow, T) + kRowWrapMin >= (sizeof(SharedRow) + 1279) / 1280 * 1280,
+// ROWOOB: the scan reads the table without clamping its address (see kRowZero); otherwise the address is clamped
+// onto the "not available" entry behind the table (one more instruction per visit; the 15-base instance, whose
+// table is too long for its wrapped addresses to clear the allocation)
+static_assert(!ROWOOB || offsetof(SharedRow, T) + kRowWrapMin >= (sizeof(SharedRow) + 1279) / 1280 * 1280,
               "wrapped table addresses must lie beyond the block's LDS allocation (granule: 1,280 bytes)");
-static_assert(kRowTBytes <= kRowWrapMin, "valid addresses stay inside the table");
+static_assert(kRowTBytes <= kRowWrapMin, "valid addresses stay inside the table, wrapped ones beyond it");
 static_assert(sizeof(SharedRow) <= 160 * 1024, "one block per CU");
 
 struct KParts {
     int ii, jj, n2;
 };
-// K = 772 jj + 4 ii + n2 (K < 2^14): jj = K / 772 by multiplication (exact for every K < 16384)
-__device__ __forceinline__ KParts k_parts(unsigned K)
+// K = kRowA jj + 4 ii + n2: jj = K / kRowA by multiplication (exact for every K a slot word can hold: checked below)
+static constexpr unsigned kRowDivMagic = ((1u << 24) + (unsigned)kRowA - 1u) / (unsigned)kRowA;
+static constexpr bool div_magic_ok()
+{
+    for (unsigned K = 0; K <= (unsigned)kEmptyRowK; ++K)
+        if (((K * kRowDivMagic) >> 24) != K / (unsigned)kRowA) return false;
+    return true;
+}
+static __device__ __forceinline__ KParts k_parts(unsigned K)
 {
     KParts p;
-    p.jj = (int)((K * 21733u) >> 24);
+    p.jj = (int)((K * kRowDivMagic) >> 24);
     const unsigned rest = K - (unsigned)p.jj * (unsigned)kRowA;
     p.ii = (int)(rest >> 2);
     p.n2 = (int)(rest & 3u);
     return p;
 }
 // coordinates of a slot word as one byte jj << 4 | ii (0xff: none)
-__device__ __forceinline__ int word_cw(int W)
+static __device__ __forceinline__ int word_cw(int W)
 {
     const KParts p = k_parts((unsigned)W >> 17);
     return (p.jj << 4) | p.ii;
 }
 // what the traceback compares: K without n2
-__device__ __forceinline__ unsigned word_sig(int W) { return ((unsigned)W >> 17) & ~3u; }
-__device__ __forceinline__ unsigned sig_of_cw(int cw) { return (unsigned)(cw >> 4) * (unsigned)kRowA + (unsigned)((cw & 15) << 2); }
-__device__ __forceinline__ int word_h(int W) { return (W & 0x7fff) - kHBias; }
+static __device__ __forceinline__ unsigned word_sig(int W) { return ((unsigned)W >> 17) & ~3u; }
+static __device__ __forceinline__ unsigned sig_of_cw(int cw) { return (unsigned)(cw >> 4) * (unsigned)kRowA + (unsigned)((cw & 15) << 2); }
+static __device__ __forceinline__ int word_h(int W) { return (W & 0x7fff) - kHBias; }
 // the f64 kernels' word (h << 14 | po << 8 | im1 << 4 | jm1) of pair_core.hpp's cand_* helpers;
 // po = pair base | 3' neighbour on oligo 1 << 2 | right neighbour on oligo 2 << 4
-__device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
+static __device__ __forceinline__ int core_of_k(unsigned K, unsigned s1, int h)
 {
     const KParts p = k_parts(K);
     const int po = (int)((s1 >> (2 * p.ii)) & 15u) | (p.n2 << 4);
     return (h << 14) | (po << 8) | (p.ii << 4) | p.jj;
 }
-__device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
+static __device__ __forceinline__ int core_word_row(int W, unsigned s1) { return core_of_k((unsigned)W >> 17, s1, word_h(W)); }
 
 struct RCell {
     unsigned C;     // per-cell minuend of the address subtraction
@@ -172,7 +191,7 @@ struct RCell {
 // Table address (byte offset) of predecessor word W seen from the cell with minuend C; a predecessor that
 // is not up-left of the cell lands on a "not available" entry.  (The clamped form: used once per cell, for the
 // winner's enthalpy; the scan itself uses scan_index().)
-__device__ __forceinline__ unsigned row_index(unsigned C, unsigned W)
+static __device__ __forceinline__ unsigned row_index(unsigned C, unsigned W)
 {
     return min((C - W) >> 15, (unsigned)kRowTBytes);
 }
@@ -183,9 +202,9 @@ struct RowBest {
     double GW;
     int G2;
 };
-__device__ __forceinline__ int best_g(const RowBest &b) { return __double2hiint(b.GW); }
-__device__ __forceinline__ int best_w(const RowBest &b) { return __double2loint(b.GW); }
-__device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
+static __device__ __forceinline__ int best_g(const RowBest &b) { return __double2hiint(b.GW); }
+static __device__ __forceinline__ int best_w(const RowBest &b) { return __double2loint(b.GW); }
+static __device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
 {
     b.G2 = med3_i32(best_g(b), b.G2, cand);   // second smallest so far
     const double cd = __hiloint2double(cand, Wp);
@@ -195,7 +214,11 @@ __device__ __forceinline__ void take_min(RowBest &b, int cand, int Wp)
 }
 
 // the scan's address: no clamp (a wrapped address lies beyond the allocation and reads 0 = not available)
-__device__ __forceinline__ unsigned scan_index(unsigned C, unsigned W) { return (C - W) >> 15; }
+static __device__ __forceinline__ unsigned scan_index(unsigned C, unsigned W)
+{
+    if constexpr (ROWOOB) return (C - W) >> 15;
+    else return min((C - W) >> 15, (unsigned)kRowTBytes);
+}
 
 // The table addresses and the (still outstanding) table values of one chunk of slots.
 struct ChunkLoad {
@@ -204,7 +227,7 @@ struct ChunkLoad {
 };
 
 template <int NS, int PC>
-__device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, const RCell &c, ChunkLoad &L)
+static __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, const RCell &c, ChunkLoad &L)
 {
 #pragma unroll
     for (int e = 0; e < kC; ++e)
@@ -220,7 +243,7 @@ __device__ __forceinline__ void chunk_issue(MSSPE_TAB_PARAMS, const char *T, con
 // which of them lie entirely in rows i-2 and above).  Two scalar words instead of two comparisons per chunk whose
 // results the compiler would keep alive, as lane masks, across the whole cell.
 template <int NS, int PC = 0>
-__device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, unsigned run, unsigned far, int near_from, const char *T,
+static __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, unsigned run, unsigned far, int near_from, const char *T,
                                               const RCell &c, RowBest &best, IBest &stk, ScanMasks &m)
 {
     if constexpr (PC * kC < NS) {
@@ -262,7 +285,7 @@ __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, unsigned run, un
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  !active: idle lane.  n_slots: the slots the
 // wave's rows take (all rows but the last, padded to the widest lane); wmax4: the widest lane's count of each base.
 template <int NS>
-__device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS, const int *gH,
+static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS, const int *gH,
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
                                                   bool decisions_only)
 {
@@ -306,10 +329,10 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
         const int jm1 = ((__ffs((int)mrem) - 1) >> 1) & 15;
         mrem &= mrem - 1;
         RCell rc;
-        rc.C = ((unsigned)((jm1 - 1) * kRowA + im1 * 60 + 3) << 17) | 0x7fffu;
+        rc.C = ((unsigned)((jm1 - 1) * kRowA + im1 * (4 * (kRowR + 1)) + 3) << 17) | 0x7fffu;
         // m2 = base left of the cell on oligo 2 (0 in column 0, where no loop can close)
         rc.yTS = sh.yts[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)];
-        rc.idxStk = ((im1 * 14 + 1) * 4 + (int)((q.s1 >> (2 * im1)) & 3u)) * 4;   // l2 = 0, i - ii = 1, 3 - n2 = base of the cell
+        rc.idxStk = ((im1 * kRowR + 1) * 4 + (int)((q.s1 >> (2 * im1)) & 3u)) * 4;   // l2 = 0, i - ii = 1, 3 - n2 = base of the cell
         // ---- all earlier slots as predecessors
         RowBest rb;
         IBest stk;
@@ -533,7 +556,7 @@ __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConst
 
 // One lock-step DP of the wave: lane = (row, col), all lanes share `row`.
 template <int NS>
-__device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, int row, int col, uint64_t pa,
+static __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, int row, int col, uint64_t pa,
                                                uint64_t pb, bool inside)
 {
     const int lane = threadIdx.x & 63;
@@ -677,7 +700,7 @@ __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntArgs &a, 
 // cell sits right of the predecessor, whose base on oligo 2 is the complement of oligo 1's at ii.  The row above the
 // cell (r == 1) takes no cell-side term at all.
 // r == 0 (same row), ii < 0, the stacked pair and loops the chemistry has no entry for: not available.
-__device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a, unsigned s1)
+static __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a, unsigned s1)
 {
     const int32_t *Tg = a.it->T;
     const int32_t *Hg = a.f.ft->H;
@@ -693,7 +716,7 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
     __syncthreads();
     for (int e = threadIdx.x; e < kRowTEntries; e += kRowThreads) {
         const int l2 = e / kRowA, rem = e - l2 * kRowA;
-        const int n2 = 3 - (rem & 3), ir = rem >> 2, i = ir / 14, r = ir - i * 14;
+        const int n2 = 3 - (rem & 3), ir = rem >> 2, i = ir / kRowR, r = ir - i * kRowR;
         const int ii = i - r, l1 = r - 1;
         int v = IntTables::kBig, hv = 0;
         bool needs_y = false;
@@ -739,7 +762,7 @@ __device__ __forceinline__ void build_row_table(SharedRow &sh, const IntArgs &a,
 }
 
 template <int NS>
-__global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
+static __device__ __forceinline__ void kernel_body(const IntArgs &a)
 {
     __shared__ SharedRow sh;
     for (int e = threadIdx.x; e < kRowGCount; e += kRowThreads) {
@@ -791,9 +814,24 @@ __global__ void __launch_bounds__(kRowThreads) k_pairs_row(IntArgs a)
     }
 }
 
+};   // struct RowKernel
+
+using Row13 = RowKernel<13, 768, 52, true>;
+using Row14 = RowKernel<14, 512, 64, false>;
+using Row15 = RowKernel<15, 512, 64, false>;
+static_assert(Row13::div_magic_ok() && Row14::div_magic_ok() && Row15::div_magic_ok(), "K / kRowA by multiply-shift");
+static_assert(Row13::kRowA == 772 && Row14::kRowA == 900 && Row15::kRowA == 964, "table strides");
+
+template <class RK>
+__global__ void __launch_bounds__(RK::kRowThreads) k_pairs_row(IntArgs a)
+{
+    RK::template kernel_body<RK::kRowSlots>(a);
+}
+
 }  // namespace
 
-int pairs_row_max_k() { return kRowK; }
+int pairs_row_max_k() { return Row15::kRowK; }
+int pairs_row_oob_max_k() { return Row13::kRowK; }   // up to here the instance without an address clamp runs (it needs the probe below)
 
 namespace {
 // The probe behind pairs_row_lds_reads_zero(), two launches.
@@ -823,11 +861,11 @@ __global__ void __launch_bounds__(256) k_lds_paint(unsigned *arrived)
     wait_for_peers(arrived, gridDim.x);
     if (paint[(threadIdx.x * 97u) % (kLdsPaintBytes / 4)] != 0xa5a5a5a5u) __builtin_trap();   // keeps the stores
 }
-__global__ void __launch_bounds__(kRowThreads) k_lds_probe(unsigned lo, unsigned hi, unsigned *arrived, unsigned *nonzero)
+__global__ void __launch_bounds__(Row13::kRowThreads) k_lds_probe(unsigned lo, unsigned hi, unsigned *arrived, unsigned *nonzero)
 {
-    __shared__ SharedRow sh;
+    __shared__ Row13::SharedRow sh;
     unsigned *fill = (unsigned *)&sh;
-    for (unsigned e = threadIdx.x; e < sizeof(SharedRow) / 4; e += blockDim.x) fill[e] = 0xffffffffu;
+    for (unsigned e = threadIdx.x; e < sizeof(Row13::SharedRow) / 4; e += blockDim.x) fill[e] = 0xffffffffu;
     __syncthreads();
     wait_for_peers(arrived, gridDim.x);
     unsigned bad = 0;
@@ -848,19 +886,19 @@ hipError_t pairs_row_lds_reads_zero(hipStream_t stream, int n_cu, bool *ok)
     {   // the kernel's real LDS size (the static_asserts speak for SharedRow; a compiler could add to it), and the
         // probe's must be the same
         hipFuncAttributes fa, fp;
-        hipError_t ea = hipFuncGetAttributes(&fa, (const void *)k_pairs_row<kRowSlots>);
+        hipError_t ea = hipFuncGetAttributes(&fa, (const void *)k_pairs_row<Row13>);
         if (ea == hipSuccess) ea = hipFuncGetAttributes(&fp, (const void *)k_lds_probe);
         if (ea != hipSuccess) return ea;
         if (fa.sharedSizeBytes != fp.sharedSizeBytes) return hipSuccess;
-        if (offsetof(SharedRow, T) + (size_t)kRowWrapMin < (fa.sharedSizeBytes + 1279) / 1280 * 1280) return hipSuccess;
+        if (offsetof(Row13::SharedRow, T) + (size_t)Row13::kRowWrapMin < (fa.sharedSizeBytes + 1279) / 1280 * 1280) return hipSuccess;
     }
     unsigned *d_flag = nullptr, h_flag[3] = {0, 0, 1};
     hipError_t e = hipMalloc((void **)&d_flag, 3 * sizeof(unsigned));
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_flag, 0, 3 * sizeof(unsigned), stream);
     if (e == hipSuccess) {
-        const unsigned lo = (unsigned)offsetof(SharedRow, T) + (unsigned)kRowWrapMin;
-        const unsigned hi = (unsigned)offsetof(SharedRow, T) + (1u << 17);
+        const unsigned lo = (unsigned)offsetof(Row13::SharedRow, T) + (unsigned)Row13::kRowWrapMin;
+        const unsigned hi = (unsigned)offsetof(Row13::SharedRow, T) + (1u << 17);
         const int grid = n_cu > 0 ? n_cu : 256;
         // (a runtime that refuses a block of the CU's whole LDS leaves the probe without the painted background:
         //  what it reads beyond its allocation is then whatever earlier kernels left there)
@@ -868,7 +906,7 @@ hipError_t pairs_row_lds_reads_zero(hipStream_t stream, int n_cu, bool *ok)
                                 (int)kLdsPaintBytes) == hipSuccess)
             hipLaunchKernelGGL(k_lds_paint, dim3(grid), dim3(256), kLdsPaintBytes, stream, d_flag);
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_lds_probe, dim3(grid), dim3(kRowThreads), 0, stream, lo, hi, d_flag + 1, d_flag + 2);
+        hipLaunchKernelGGL(k_lds_probe, dim3(grid), dim3(Row13::kRowThreads), 0, stream, lo, hi, d_flag + 1, d_flag + 2);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost, stream);
@@ -893,7 +931,7 @@ bool pairs_row_tables_ok(const IntTables &it)
 hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsigned long long *reasons, int n_cu,
                             hipStream_t stream)
 {
-    if (a.k > kRowK || a.k < 2) return hipErrorInvalidValue;
+    if (a.k > Row15::kRowK || a.k < 2) return hipErrorInvalidValue;
     IntArgs x;
     FastArgs &f = x.f;
     f.ft = a.ft;
@@ -917,12 +955,15 @@ hipError_t launch_pairs_row(const PairKernelArgs &a, const IntTables *it, unsign
     x.stat_off = 0;
     x.work_counter = a.work_counter;
     const long ncolg = (a.col1 - a.col0 + 63) / 64;
-    const long items = ((ncolg + kSegGroups - 1) / kSegGroups) * (long)(a.row1 - a.row0);
+    const long items = ((ncolg + Row13::kSegGroups - 1) / Row13::kSegGroups) * (long)(a.row1 - a.row0);
     if (items <= 0) return hipSuccess;
     if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
     // one persistent block per CU (about 153 KB of LDS each)
     const int grid = (int)(items < (long)n_cu ? items : (long)n_cu);
-    hipLaunchKernelGGL((k_pairs_row<kRowSlots>), dim3(grid), dim3(kRowThreads), 0, stream, x);
+    // up to 13 bases: three waves per SIMD, 52 stored cells, no address clamp; 14 / 15 bases: two waves, 56 / 64 cells
+    if (a.k <= Row13::kRowK) hipLaunchKernelGGL((k_pairs_row<Row13>), dim3(grid), dim3(Row13::kRowThreads), 0, stream, x);
+    else if (a.k <= Row14::kRowK) hipLaunchKernelGGL((k_pairs_row<Row14>), dim3(grid), dim3(Row14::kRowThreads), 0, stream, x);
+    else hipLaunchKernelGGL((k_pairs_row<Row15>), dim3(grid), dim3(Row15::kRowThreads), 0, stream, x);
     return hipGetLastError();
 }
 

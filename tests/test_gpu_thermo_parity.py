@@ -293,7 +293,7 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k
     21-mers through the split-table kernel and, with that one switched off, through the matrix mode
     of the one-wave-per-pair kernel."""
     import torch
-    eng.set_option("split_min_k", 99 if no_split else 15)
+    eng.set_option("split_min_k", 99 if no_split else 16)
     n = 200
     pool_ascii = m.synth.random_pool(n, k, seed=78)
     d_pool = torch.from_numpy(m.pack_oligos(pool_ascii).view(np.int64)).cuda()
@@ -308,7 +308,7 @@ def test_row_and_column_sub_blocks(eng, m, oracle, oracle_tables, monkeypatch, k
         torch.cuda.synchronize()
     finally:
         eng.reset_stream()
-        eng.set_option("split_min_k", 15)
+        eng.set_option("split_min_k", 16)
     _, dg, cf, _ = oracle.pool_pairs(oracle_tables, pool_ascii)
     np.testing.assert_array_equal(d_dg.cpu().numpy(), dg[r0:r1, c0:c1])
     want = np.zeros(n, dtype=np.int64)
