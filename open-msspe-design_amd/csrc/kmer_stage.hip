@@ -72,6 +72,16 @@ __device__ __forceinline__ uint32_t row_of(uint32_t seg, uint32_t P, uint32_t G)
     return (seg % P) * G + seg / P;
 }
 
+// The word id of window position q of the segment in partition-major row `row`: kid_of_inst is laid out
+// [partition][window position][genome], so that the 64 genomes a wave handles at one window position are 64
+// neighbouring words -- for the index pass that writes them (a word's postings are the same window position of many
+// genomes, in ascending genome order) and for the cover and marking passes that read them with lane = genome.
+__device__ __forceinline__ size_t inst_slot(uint32_t row, uint32_t q, uint32_t per, uint32_t G)
+{
+    const uint32_t part = row / G, genome = row - part * G;
+    return ((size_t)part * per + q) * G + genome;
+}
+
 __device__ __forceinline__ int base2(uint8_t c)
 {
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
@@ -206,7 +216,7 @@ __global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *hea
     const uint64_t k = key[i];
     const uint32_t inst = val[i];
     const uint32_t seg = inst / (uint32_t)per, q = inst % (uint32_t)per;
-    const size_t slot = (size_t)row_of(seg, (uint32_t)P, (uint32_t)G) * per + q;
+    const size_t slot = ((size_t)(seg % (uint32_t)P) * per + q) * (uint32_t)G + seg / (uint32_t)P;   // inst_slot of its row
     if (k == sentinel) {
         kid_of_inst[slot] = -1;
         return;
@@ -383,8 +393,8 @@ __global__ void __launch_bounds__(256) k_live_all(const Status *st, int32_t *liv
 // Behind a new candidate list: which live segments hold a word of the list (marked), and how many of them each
 // partition has (live_part).  A word of the list can only lose marked segments, and after a cover of f live segments
 // of partition p every word living in p has at most live_part[p] - f left: k_fast's bound.  (Segments that hold rare
-// words only -- most of what is left late in the loop -- do not count.)  One wave per segment, lane = window position;
-// rows are partition-major, so a wave's consecutive rows share a partition and one atomic serves many.
+// words only -- most of what is left late in the loop -- do not count.)  A wave takes 64 consecutive rows, lane = row
+// (rows are partition-major: mostly one partition, one atomic), and walks the window positions.
 __global__ void __launch_bounds__(256) k_mark(const Status *st, const int32_t *kid_of_inst, const uint8_t *ignored,
                                               const uint32_t *cand_flag, int n_seg, int per, int G, uint8_t *marked,
                                               int32_t *live_part)
@@ -393,29 +403,31 @@ __global__ void __launch_bounds__(256) k_mark(const Status *st, const int32_t *k
     const uint32_t epoch = st->epoch;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    const int rows_per = (n_seg + n_waves - 1) / n_waves;   // a contiguous run of rows per wave
-    const int r0 = wave * rows_per, r1 = min(n_seg, r0 + rows_per);
-    int acc = 0, acc_part = -1;
-    for (int row = r0; row < r1; ++row) {
+    for (int r0 = wave * 64; r0 < n_seg; r0 += n_waves * 64) {   // wave-uniform
+        const int row = r0 + lane;
+        const bool in = row < n_seg;
+        const int part = in ? row / G : -1;
         bool any = false;
-        if (!ignored[row]) {
-            for (int q0 = 0; q0 < per; q0 += 64) {
-                const int q = q0 + lane;
-                const int32_t kid = q < per ? kid_of_inst[(size_t)row * per + q] : -1;
-                any = any || (kid >= 0 && cand_flag[kid] == epoch);
+        if (in && !ignored[row]) {
+            const int32_t *col = kid_of_inst + ((size_t)part * per) * G + (row - part * G);
+            for (int q = 0; q < per && !any; q += 4) {   // four loads in flight; a marked segment stops early
+                int32_t kid[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kid[j] = q + j < per ? col[(size_t)(q + j) * G] : -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) any = any || (kid[j] >= 0 && cand_flag[kid[j]] == epoch);
             }
-            any = __ballot(any) != 0ull;
         }
-        if (lane == 0) marked[row] = any ? 1 : 0;
-        const int part = row / G;
-        if (part != acc_part) {
-            if (acc && lane == 0) atomicAdd(&live_part[acc_part], acc);
-            acc = 0;
-            acc_part = part;
+        if (in) marked[row] = any ? 1 : 0;
+        unsigned long long m = __ballot(any);
+        while (m) {   // one atomic per distinct partition of the 64 rows (one, at a boundary two)
+            const int l = __ffsll((long long)m) - 1;
+            const int pl = __builtin_amdgcn_readlane(part, l);
+            const unsigned long long same = __ballot(any && part == pl);
+            if (lane == l) atomicAdd(&live_part[pl], (int)__popcll(same));
+            m &= ~same;
         }
-        acc += any ? 1 : 0;
     }
-    if (acc && lane == 0) atomicAdd(&live_part[acc_part], acc);
 }
 
 // winner = highest score, then smallest word (= smallest id: ids follow the sorted key order).
@@ -666,6 +678,7 @@ constexpr int kEMax = 2048;            // words scored per iteration at most (mo
 constexpr int kETarget = 128;          // ... and aimed at
 constexpr int kOwn = kEMax / kSelectGrid;   // a block's share of E per class
 constexpr int kMaxPick = 64;           // winners per iteration at most
+constexpr int kCoverGrid = 512;        // k_cover_multi: two 1,024-thread blocks per CU, 16 chunks of 64 postings each at a time
 constexpr int kHistBins = 256;         // counts from the maximum down that E may reach
 constexpr int kNarrowMaxP = 8192;      // 34 partition bitmaps in LDS
 
@@ -1038,7 +1051,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         const int nt = min(n_task, kFastTasks);
         for (int id = tid; id < nt * per; id += 1024) {
             const int t = id / per, q = id - t * per;
-            if ((uint32_t)kid_of_inst[(size_t)task_row[t] * per + q] == task_kid[t]) atomicOr(&hitmask[task_j[t]], 1u << task_bit[t]);
+            if ((uint32_t)kid_of_inst[inst_slot(task_row[t], (uint32_t)q, (uint32_t)per, (uint32_t)G)] == task_kid[t]) atomicOr(&hitmask[task_j[t]], 1u << task_bit[t]);
         }
     }
     const int n_ent = n_ent_sh;
@@ -1601,37 +1614,24 @@ __global__ void __launch_bounds__(1024) k_prefix(Status *st, PickState *ps, cons
 }
 
 // Cover every segment that holds a winner: take one off the live count of every word of the segments that are
-// covered now.  A block takes 64 postings at a time.  Wave 0 does the per-posting bookkeeping; the four waves
-// then gather the 64 segments' word ids into an LDS tile (64 window positions per pass, 16 loads per
-// thread in flight) and split the window positions between them with lane = posting: neighbouring
-// postings are the same window of near-identical genomes, so equal targets are merged across the
-// wave before the atomic (same-address atomics serialise in L2).
-struct CoverShared {
-    int32_t tile[64 * 65];
-    uint32_t rows[64];   // partition-major row of each posting, ~0u: nothing to do
-    int any_live;
-};
-
-// the count updates of the 64 postings whose rows are in sh.rows (all threads of the block)
-__device__ __forceinline__ void cover_rows(CoverShared &sh, int per, const int32_t *kid_of_inst, int32_t *count)
+// covered now.  A WAVE takes 64 postings at a time, lane = posting: it does the per-posting bookkeeping, then walks
+// the window positions and reads the 64 segments' word ids straight from the position-major table (neighbouring
+// postings are the same window of neighbouring genomes: neighbouring words, and mostly the SAME word id, so equal
+// targets are merged across the wave before the atomic -- same-address atomics serialise in L2).  No block barrier:
+// every wave of the chip has its own chunk in flight.
+__device__ __forceinline__ void cover_wave(uint32_t row, bool ok, int per, int G, const int32_t *kid_of_inst, int32_t *count)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int q0 = 0; q0 < per; q0 += 64) {
-        int32_t v[16];
+    constexpr int kDeep = 8;   // window positions whose loads are in flight together
+    const int lane = threadIdx.x & 63;
+    const uint32_t part = ok ? row / (uint32_t)G : 0u;
+    const int32_t *col = kid_of_inst + ((size_t)part * per) * G + (ok ? row - part * (uint32_t)G : 0u);
+    for (int q0 = 0; q0 < per; q0 += kDeep) {   // wave-uniform
+        int32_t v[kDeep];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {   // 16 loads per thread in flight before the LDS stores
-            const int r = 4 * j + wave, q = q0 + lane;
-            const uint32_t row_r = sh.rows[r];
-            const bool ok = row_r != 0xffffffffu && q < per;
-            const int32_t x = kid_of_inst[ok ? (size_t)row_r * per + q : 0];
-            v[j] = ok ? x : -1;
-        }
+        for (int j = 0; j < kDeep; ++j) v[j] = (ok && q0 + j < per) ? col[(size_t)(q0 + j) * G] : -1;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sh.tile[(4 * j + wave) * 65 + lane] = v[j];
-        __syncthreads();
-        const int nq = min(64, per - q0);
-        for (int qq = wave; qq < nq; qq += 4) {
-            const int32_t k2 = sh.tile[lane * 65 + qq];
+        for (int j = 0; j < kDeep; ++j) {
+            const int32_t k2 = v[j];
             // merge the common words of this window position (up to three rounds: the
             // consensus word and its most frequent variants), the rest go one by one
             unsigned long long mk = __ballot(k2 >= 0);
@@ -1644,7 +1644,55 @@ __device__ __forceinline__ void cover_rows(CoverShared &sh, int per, const int32
             }
             if ((mk >> lane) & 1ull) atomicSub(&count[k2], 1);
         }
-        __syncthreads();
+    }
+}
+
+// The same with the count updates collected in a table in LDS first (k_cover_multi: the 16 waves of a block take 16
+// neighbouring chunks of one winner and meet the same words over and over -- the consensus word of a window position
+// and its variants; measured on 64 winners of 8,000 postings each, the global atomics were three quarters of the
+// kernel's time).  Open addressing, linear probing, keys claimed with a compare-and-swap; a lane that finds no place
+// within kProbeMax steps (a table fuller than it should ever be) sends its update to memory directly.
+constexpr int kCoverTbl = 4096;    // entries (32 KB): a block's 1,024 segments x ~40 window positions hold ~1,000 distinct words
+constexpr int kProbeMax = 32;
+
+__device__ __forceinline__ void table_sub(int32_t *tkey, int32_t *tval, int32_t kid, int n, int32_t *count)
+{
+    unsigned h = ((unsigned)kid * 2654435761u) >> 20;
+    for (int step = 0; step < kProbeMax; ++step) {
+        const int32_t old = atomicCAS(&tkey[h], -1, kid);
+        if (old == -1 || old == kid) {
+            atomicAdd(&tval[h], n);
+            return;
+        }
+        h = (h + 1u) & (unsigned)(kCoverTbl - 1);
+    }
+    atomicSub(&count[kid], n);
+}
+
+__device__ __forceinline__ void cover_wave_table(uint32_t row, bool ok, int per, int G, const int32_t *kid_of_inst,
+                                                 int32_t *count, int32_t *tkey, int32_t *tval)
+{
+    constexpr int kDeep = 8;
+    const int lane = threadIdx.x & 63;
+    const uint32_t part = ok ? row / (uint32_t)G : 0u;
+    const int32_t *col = kid_of_inst + ((size_t)part * per) * G + (ok ? row - part * (uint32_t)G : 0u);
+    for (int q0 = 0; q0 < per; q0 += kDeep) {   // wave-uniform
+        int32_t v[kDeep];
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) v[j] = (ok && q0 + j < per) ? col[(size_t)(q0 + j) * G] : -1;
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) {
+            const int32_t k2 = v[j];
+            unsigned long long mk = __ballot(k2 >= 0);
+            if (mk) {   // the window position's most likely word: one update for all its lanes
+                const int l = __ffsll((long long)mk) - 1;
+                const int32_t kl = __builtin_amdgcn_readlane(k2, l);
+                const unsigned long long same = __ballot(k2 == kl);
+                if (lane == l) table_sub(tkey, tval, kl, (int)__popcll(same), count);
+                mk &= ~same;
+            }
+            if ((mk >> lane) & 1ull) table_sub(tkey, tval, k2, 1, count);
+        }
     }
 }
 
@@ -1673,46 +1721,38 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
                                                const uint64_t *ukeys, uint64_t *out_key,
                                                uint32_t *out_freq, int32_t *live_part, const uint8_t *marked)
 {
-    __shared__ CoverShared sh;
     if (st->stop) return;
     const uint32_t it1 = (uint32_t)st->n_win + 1u;   // unique stamp of this iteration
     const unsigned long long best = st->best;
     const uint32_t kid = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
     const uint32_t b = post_off[kid], e = post_off[kid + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = b + blockIdx.x * 64u; base < e; base += gridDim.x * 64u) {
-        bool rep = false;          // wave 0: this lane speaks for its partition
+    for (uint32_t base = b + (blockIdx.x * 4u + wave) * 64u; base < e; base += gridDim.x * 256u) {   // wave-uniform
+        bool rep = false;          // this lane speaks for its partition
         uint32_t old_stamp = it1;
         int part = -1;
-        if (wave == 0) {
-            const uint32_t i = base + lane;
-            uint32_t row = 0;
-            bool live = false;
-            if (i < e) {
-                const uint32_t seg = post[i];
-                part = (int)(seg % (uint32_t)P);
-                row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
-                live = !ignored[row];
-                ignored[row] = 1;   // a segment appears once per posting list: no race
-            }
-            sh.rows[lane] = live ? row : 0xffffffffu;
-            const unsigned long long lives = __ballot(live);
-            if (lane == 0) sh.any_live = lives != 0ull;
-            take_live(live_part, live && marked[row], part, lane);
-            unsigned long long m = __ballot(part >= 0);
-            while (m) {   // once per distinct partition of the wave
-                const int l = __ffsll((long long)m) - 1;
-                const int pl = __builtin_amdgcn_readlane(part, l);
-                m &= ~__ballot(part == pl);
-                rep = rep || lane == l;
-            }
-            // all the partitions at once; the answer is looked at after the count updates are on their way
-            if (rep) old_stamp = atomicExch(&stamp[part], it1);
+        const uint32_t i = base + lane;
+        uint32_t row = 0;
+        bool live = false;
+        if (i < e) {
+            const uint32_t seg = post[i];
+            part = (int)(seg % (uint32_t)P);
+            row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
+            live = !ignored[row];
+            ignored[row] = 1;   // a segment appears once per posting list: no race
         }
-        __syncthreads();
-        if (sh.any_live) cover_rows(sh, per, kid_of_inst, count);
+        take_live(live_part, live && marked[row], part, lane);
+        unsigned long long m = __ballot(part >= 0);
+        while (m) {   // once per distinct partition of the wave
+            const int l = __ffsll((long long)m) - 1;
+            const int pl = __builtin_amdgcn_readlane(part, l);
+            m &= ~__ballot(part == pl);
+            rep = rep || lane == l;
+        }
+        // all the partitions at once; the answer is looked at after the count updates are on their way
+        if (rep) old_stamp = atomicExch(&stamp[part], it1);
+        if (__ballot(live)) cover_wave(row, live, per, G, kid_of_inst, count);
         if (rep && old_stamp != it1) atomicAdd(&coverage[part], 1u);   // first posting of the partition this iteration
-        __syncthreads();   // sh.rows / any_live are rewritten by the next group
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1736,27 +1776,45 @@ __global__ void __launch_bounds__(256) k_cover(Status *st, const uint32_t *post_
 // prefix), so the count updates of different winners never meet in a segment -- with one exception, a
 // several-partition word accepted with a re-computed key, which is why a segment is claimed with an atomic before
 // it is covered (below).  (The partition coverage is k_fast's / k_prefix's.)
-__global__ void __launch_bounds__(256) k_cover_multi(const PickState *ps, const uint32_t *post_off,
-                                                     const uint32_t *post, uint8_t *ignored, int P, int G, int per,
-                                                     const int32_t *kid_of_inst, int32_t *count, int32_t *live_part,
-                                                     const uint8_t *marked)
+__global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const uint32_t *post_off,
+                                                      const uint32_t *post, uint8_t *ignored, int P, int G, int per,
+                                                      const int32_t *kid_of_inst, int32_t *count, int32_t *live_part,
+                                                      const uint8_t *marked)
 {
-    __shared__ CoverShared sh;
-    __shared__ uint32_t cum_s[kMaxPick + 1], kid_s[kMaxPick];
+    constexpr unsigned kSpan = 16;   // chunks per work item: one per wave
+    __shared__ int32_t tkey[kCoverTbl], tval[kCoverTbl];
+    __shared__ uint32_t cum_s[kMaxPick + 1], kid_s[kMaxPick], span_s[kMaxPick + 1];
     const unsigned np = ps->n_pick;
     if (np == 0) return;
-    if (threadIdx.x <= np) cum_s[threadIdx.x] = ps->cum[threadIdx.x];
-    if (threadIdx.x < np) kid_s[threadIdx.x] = ps->kid[threadIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((unsigned)tid <= np) cum_s[tid] = ps->cum[tid];
+    if ((unsigned)tid < np) kid_s[tid] = ps->kid[tid];
+    for (int e = tid; e < kCoverTbl; e += 1024) {
+        tkey[e] = -1;
+        tval[e] = 0;
+    }
     __syncthreads();
-    const unsigned total = cum_s[np];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {
-        unsigned j = 0;   // the winner this chunk belongs to (block-uniform)
-        while (j + 1 < np && cum_s[j + 1] <= item) ++j;
-        const uint32_t kid = kid_s[j];
-        const uint32_t base = post_off[kid] + (item - cum_s[j]) * 64u, e = post_off[kid + 1];
-        if (wave == 0) {
-            const uint32_t i = base + lane;
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (unsigned j = 0; j < np; ++j) {
+            span_s[j] = acc;
+            acc += (cum_s[j + 1] - cum_s[j] + kSpan - 1) / kSpan;
+        }
+        span_s[np] = acc;
+    }
+    __syncthreads();
+    const unsigned total = span_s[np];
+    for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {   // block-uniform
+        unsigned lo = 0, hi = np;   // the winner this span belongs to: the last j with span[j] <= item
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (span_s[mid] <= item) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t kid = kid_s[lo];
+        const unsigned chunk = (item - span_s[lo]) * kSpan + (unsigned)wave;
+        if (chunk < cum_s[lo + 1] - cum_s[lo]) {   // wave-uniform
+            const uint32_t i = post_off[kid] + chunk * 64u + lane, e = post_off[kid + 1];
             uint32_t row = 0;
             int part = -1;
             bool live = false;
@@ -1772,14 +1830,19 @@ __global__ void __launch_bounds__(256) k_cover_multi(const PickState *ps, const 
                 const unsigned old = atomicOr(reinterpret_cast<unsigned *>(ignored + (row & ~3u)), 1u << sh8);
                 live = ((old >> sh8) & 0xffu) == 0u;
             }
-            sh.rows[lane] = live ? row : 0xffffffffu;
-            const unsigned long long lives = __ballot(live);
-            if (lane == 0) sh.any_live = lives != 0ull;
             take_live(live_part, live && marked[row], part, lane);
+            if (__ballot(live)) cover_wave_table(row, live, per, G, kid_of_inst, count, tkey, tval);
         }
         __syncthreads();
-        if (sh.any_live) cover_rows(sh, per, kid_of_inst, count);
-        __syncthreads();   // sh.rows / any_live are rewritten by the next item
+        for (int e = tid; e < kCoverTbl; e += 1024) {   // the table goes to memory and is empty again
+            const int32_t k = tkey[e];
+            if (k >= 0) {
+                atomicSub(&count[k], tval[e]);
+                tkey[e] = -1;
+                tval[e] = 0;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -2081,7 +2144,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
                            ignored, coverage, (int)P, n_seq, res_key, res_kid, res_bits);
         hipLaunchKernelGGL(k_prefix, dim3(1), dim3(1024), 0, s_, st, ps, res_key, res_kid, res_bits, post_off, ukeys,
                            coverage, out_key, out_freq, out_trace, (int)P);
-        hipLaunchKernelGGL(k_cover_multi, dim3(256), dim3(256), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
+        hipLaunchKernelGGL(k_cover_multi, dim3(kCoverGrid), dim3(1024), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
                            kid_of_inst, count, live_part, marked);
     };
     auto enqueue_narrow = [&](hipStream_t s_, int /*node*/) {
@@ -2091,7 +2154,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         hipLaunchKernelGGL(k_fast, dim3(1), dim3(1024), 0, s_, st, ps, count, cand, word_part, word_multi, multi,
                            live_part, coverage, post_off, ukeys, kid_of_inst, per, n_seq, out_key, out_freq, out_trace,
                            (int)P);
-        hipLaunchKernelGGL(k_cover_multi, dim3(256), dim3(256), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
+        hipLaunchKernelGGL(k_cover_multi, dim3(kCoverGrid), dim3(1024), 0, s_, ps, post_off, post, ignored, (int)P, n_seq, per,
                            kid_of_inst, count, live_part, marked);
     };
     // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration)
