@@ -300,7 +300,10 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
             if (kRebuild) {
                 // head of a batch of the candidate-list loop: counts only fall, so until the maximum drops
                 // below theta the winner and everything tied with it are among the words collected now
-                st->theta = max(2, mf / 2);
+#ifndef THETA_DIV
+#define THETA_DIV 2
+#endif
+                st->theta = max(2, mf / THETA_DIV);
                 st->n_cand = 0;
                 st->n_mcand = 0;
                 st->epoch += 1;
@@ -718,6 +721,7 @@ constexpr int kFastMaxP = 2048;    // entries ranked by counting, n^2 / 1024 ste
 constexpr int kMultiParts = 4;     // partitions of a several-partition word the fast path keeps
 constexpr int kFastTop = 256;      // entries of the order the walk may look at (accepted + passed over)
 constexpr int kFastEnt = kFastMaxP + (int)kMaxMulti;
+constexpr int kFastMiCache = 64;   // several-partition records the walk finds in LDS
 
 constexpr int kMinorSegs = 4;      // a partition with at most this many live postings of the word: their segments are kept
 
@@ -887,6 +891,12 @@ struct WalkWord {
     unsigned long long key;   // count << 32 | score bits, as of now
 };
 
+#ifdef FAST_CLOCK
+__device__ unsigned long long g_fast_clock[16];
+#define FCLK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_fast_clock[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define FCLK(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const int32_t *count, const uint32_t *cand,
                                                const uint16_t *word_part, const uint8_t *word_multi,
                                                const MultiInfo *multi, const int32_t *live_part, uint32_t *coverage,
@@ -907,10 +917,25 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     __shared__ uint32_t task_row[kFastTasks], task_kid[kFastTasks];
     __shared__ unsigned short task_bit[kFastTasks], task_j[kFastTasks];
     __shared__ int top[kFastTop];
+    __shared__ WalkWord walk_s[kMaxPend + 1];        // the walk's waiting words and the word in hand (one thread's; in
+                                                     // private memory every access was a trip to scratch: 1 us per winner)
+    __shared__ int rank_s[kFastEnt];                 // entries ahead of entry i (summed over the threads that share it)
+    __shared__ unsigned long long ent_word[kFastEnt]; // the walk's global data, fetched by all the threads before it:
+    __shared__ unsigned ent_chunks[kFastEnt];        //   an entry's word and 64-posting chunks (top entries only),
+    __shared__ int lp_s[kFastMaxP];                  //   the partitions' live segments,
+    __shared__ MultiInfo mi_s[kFastMiCache];         //   the several-partition records of the first such entries
+    __shared__ unsigned char mi_slot[kMaxMulti];     //   (mi_slot[j]: where multi[j] is, 0xff: not cached)
+    __shared__ int n_mi_s;
     __shared__ unsigned short bump[kMaxPick * kMultiParts];   // partitions whose coverage goes up
     __shared__ int red[16];
     __shared__ int n_ent_sh, n_bump, n_task;
+    __shared__ int ws_r, ws_bound, ws_np, ws_nb, ws_nwin, ws_stop_next, ws_stop_now, ws_done;   // the walk's state between turns
+    __shared__ unsigned ws_chunks;
+    __shared__ uint32_t ws_last;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef FAST_CLOCK
+    unsigned long long t_prev = wall_clock64();
+#endif
     // (single block, and the only writer of the loop's flags besides k_prefix, which does not run when this did)
     const int stop = st->stop, rebuild_state = st->need_rebuild;
     const unsigned n_cand = st->n_cand, n_mcand = st->n_mcand;
@@ -927,6 +952,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         n_ent_sh = 0;
         n_bump = 0;
         n_task = 0;
+        n_mi_s = 0;
     }
     if (stop || rebuild_state == 1 || want_general0) {   // the host looks at these between batches
         if (tid == 0) st->it_idle += 1;
@@ -954,8 +980,10 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         }
         return;
     }
+    FCLK(0);
     for (int e = tid; e < P; e += 1024) {
         lead[e] = 0ull;
+        lp_s[e] = live_part[e];
         second[e] = 0;
         ub[e] = -1;
         who[e] = kByMulti;
@@ -965,6 +993,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     for (unsigned e = (unsigned)tid; e < n_mcand; e += 1024) {
         hitmask[e] = 0u;
         hit_known[e] = 1;
+        mi_slot[e] = 0xff;
     }
     __syncthreads();
     int m = 0;   // highest count of all the candidates
@@ -981,6 +1010,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+    FCLK(1);
     if (m < theta) {   // a word outside the list may be ahead now
         if (tid == 0) st->need_rebuild = 1;
         return;
@@ -995,6 +1025,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         if (kid != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull)) atomicMax(&second[p], count[kid]);
     }
     __syncthreads();
+    FCLK(2);
     // the entries: leaders with a count of at least theta (nothing below it may be accepted from this list) ...
     for (int p0 = 0; p0 < P; p0 += 1024) {
         const int p = p0 + tid;
@@ -1055,200 +1086,365 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         }
     }
     const int n_ent = n_ent_sh;
-    for (int i = tid; i < n_ent; i += 1024) {   // rank by counting; equal (count, score): the smaller word first
-        const unsigned long long ki = lkey[i];
-        const uint32_t di = lkid[i];
-        int rank = 0;
-        for (int j = 0; j < n_ent; ++j) {
-            const unsigned long long kj = lkey[j];
-            rank += (kj > ki || (kj == ki && lkid[j] < di)) ? 1 : 0;
-        }
-        if (rank < kFastTop) top[rank] = i;
-    }
+    __syncthreads();
+    FCLK(3);
+    // rank by counting; equal (count, score): the smaller word first.  1024 / n_ent threads share an entry.
+    for (int i = tid; i < n_ent; i += 1024) rank_s[i] = 0;
     __syncthreads();
     {
-        // The walk below is one thread's, and every global load in it would be a dependent one: all the threads touch what
-        // it will read (the entries' words, posting offsets and several-partition records, the partitions' live counts and
-        // coverage) so that it finds them in this CU's L1.
+        const int share = max(1, 1024 / max(1, n_ent)), piece = (n_ent + share - 1) / share;
+        for (int t = tid; t < n_ent * share; t += 1024) {
+            const int i = t / share, j0 = (t - i * share) * piece, j1 = min(n_ent, j0 + piece);
+            const unsigned long long ki = lkey[i];
+            const uint32_t di = lkid[i];
+            int rank = 0;
+            for (int j = j0; j < j1; ++j) {
+                const unsigned long long kj = lkey[j];
+                rank += (kj > ki || (kj == ki && lkid[j] < di)) ? 1 : 0;
+            }
+            if (rank) atomicAdd(&rank_s[i], rank);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_ent; i += 1024)
+        if (rank_s[i] < kFastTop) top[rank_s[i]] = i;
+    __syncthreads();
+    FCLK(4);
+    {
+        // The walk below is one thread's, and every global load in it would be a dependent one (about 200 ns each, six per
+        // winner when it read them itself): all the threads fetch what it will read -- the entries' words and posting-list
+        // lengths into LDS, the several-partition records and the coverage into this CU's L1.
         unsigned sink = 0;
         const int lim = min(n_ent, kFastTop);
         for (int r = tid; r < lim; r += 1024) {
             const int i = top[r];
             const uint32_t kid = lkid[i];
-            sink += (unsigned)ukeys[kid] + post_off[kid] + post_off[kid + 1];
+            ent_word[i] = ukeys[kid];
+            ent_chunks[i] = (post_off[kid + 1] - post_off[kid] + 63u) / 64u;
             if (lwho[i] & 0x8000u) {
-                const unsigned *mp = reinterpret_cast<const unsigned *>(&multi[lwho[i] & 0x7fffu]);
-                sink += mp[0] + mp[16] + mp[sizeof(MultiInfo) / 4 - 1];
+                const int at = atomicAdd(&n_mi_s, 1);   // (in no particular order: whichever 64 come first)
+                if (at < kFastMiCache) mi_slot[lwho[i] & 0x7fffu] = (unsigned char)at;
             }
         }
-        for (int p = tid; p < P; p += 1024) sink += (unsigned)live_part[p] + coverage[p];
+        __syncthreads();
+        static_assert(sizeof(MultiInfo) % 4 == 0, "copied word by word");
+        constexpr int kMiWords = (int)(sizeof(MultiInfo) / 4);
+        for (int t = tid; t < lim * 32; t += 1024) {   // 32 threads per entry
+            const int i = top[t >> 5];
+            if (!(lwho[i] & 0x8000u)) continue;
+            const int j = lwho[i] & 0x7fffu, slot = mi_slot[j];
+            if (slot == 0xff) continue;
+            const unsigned *src = reinterpret_cast<const unsigned *>(&multi[j]);
+            unsigned *dst = reinterpret_cast<unsigned *>(&mi_s[slot]);
+            for (int wd = t & 31; wd < kMiWords; wd += 32) dst[wd] = src[wd];
+        }
+        for (int p = tid; p < P; p += 1024) sink += coverage[p];
         if (sink == 0x9e3779b9u) red[0] = (int)sink;   // (keeps the loads)
     }
     __syncthreads();
+    FCLK(5);
+    const int min_freq = st->min_freq;
+    const uint32_t it_now = (uint32_t)(st->it_fast + st->it_general + 1);
+    const int limit = min(n_ent, kFastTop);
     if (tid == 0) {
-        int n_win = n_win0, np = 0, nb = 0, stop_next = stop_next0, stop_now = 0, bound = 0;
-        unsigned chunks = 0;
-        const int min_freq = st->min_freq, limit = min(n_ent, kFastTop);
-        WalkWord pend[kMaxPend];
-        int npend = 0, r = 0;
-        while (np < kMaxPick) {
-            // the next entry of the order: the list's, or a waiting word whose new key is ahead of it
-            int pk = -1;
-            for (int q = 0; q < npend; ++q)
-                if (pk < 0 || pend[q].key > pend[pk].key ||
-                    (pend[q].key == pend[pk].key && lkid[pend[q].ent] < lkid[pend[pk].ent]))
-                    pk = q;
-            const int mi_i = r < limit ? top[r] : -1;
-            if (pk < 0 && mi_i < 0) break;
-            bool from_pend = mi_i < 0;
-            if (pk >= 0 && mi_i >= 0)
-                from_pend = pend[pk].key > lkey[mi_i] || (pend[pk].key == lkey[mi_i] && lkid[pend[pk].ent] < lkid[mi_i]);
-            WalkWord w;
-            if (from_pend) {
-                w = pend[pk];
-                pend[pk] = pend[--npend];
-            } else {
-                ++r;
-                w.ent = mi_i;
-                w.key = lkey[mi_i];
-                w.j = (lwho[mi_i] & 0x8000u) ? (int)(lwho[mi_i] & 0x7fffu) : -1;
-                w.rem = 0xffffu;
-                for (int x = 0; x < kMultiParts; ++x) {
-                    w.cnt[x] = w.j >= 0 ? multi[w.j].live_cnt[x] : 0;
-                    w.seen[x] = 0;
+        ws_r = 0;
+        ws_bound = 0;
+        ws_np = 0;
+        ws_nb = 0;
+        ws_chunks = 0u;
+        ws_nwin = n_win0;
+        ws_stop_next = stop_next0;
+        ws_stop_now = 0;
+        ws_done = 0;
+        ws_last = 0u;
+    }
+    __syncthreads();
+    // The order is walked in turns.  Wave 0 takes runs of partition LEADERS, for which the walk is a scan: lane r takes
+    // the entry of rank r; a leader whose partition is untouched is accepted when its count is above the bound its
+    // predecessors leave -- the running maximum of what each of them can still leave behind: min(live segments its
+    // partition keeps, its partition's runner-up) for an accepted leader, min(count, live segments left) for a leader
+    // whose partition a several-partition winner has touched (passed over) -- and the first one that is not ends the
+    // iteration: a prefix maximum and two ballots, the accepted lanes record their winners side by side.  Thread 0 takes
+    // what the scan cannot: several-partition words (their keys are re-computed against what has been accepted, and may
+    // wait in `pend`), and the loop's stop rules.  (All of it was thread 0's once: 1 us per entry, dependent LDS trips.)
+    int npend = 0;   // thread 0's, across its turns
+    for (int turn = 0; turn < kFastTop + 2; ++turn) {   // block-uniform; every turn finishes the iteration or takes an entry
+        if (wave == 0) {
+            const int r0 = ws_r, np0 = ws_np, nb0 = ws_nb, nwin0 = ws_nwin, bound0 = ws_bound, sn0 = ws_stop_next;
+            const unsigned chunks0 = ws_chunks;
+            const int idx = r0 + lane;
+            const int i = idx < limit ? top[idx] : -1;
+            const bool leader = i >= 0 && !(lwho[i] & 0x8000u);
+            const unsigned long long others = __ballot(!leader);
+            const int n_lead = others ? __ffsll((long long)others) - 1 : 64;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int f = 0, p = 0, b = 0;
+            uint32_t kid = 0;
+            unsigned ch = 0;
+            bool fresh = false;   // a leader whose partition nothing has touched in this iteration
+            if (lane < n_lead) {
+                f = (int)(lkey[i] >> 32);
+                p = lwho[i];
+                kid = lkid[i];
+                const int u = ub[p];
+                fresh = u < 0;
+                b = fresh ? min(lp_s[p] - f, max(second[p], theta - 1)) : min(f, u);
+                ch = fresh ? ent_chunks[i] : 0u;
+            }
+            const unsigned long long fresh_m = __ballot(fresh);
+            int pm = b;   // inclusive prefix maximum of b, inclusive prefix sum of the fresh leaders' chunks
+            unsigned cs = ch;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(pm, off);
+                const unsigned u = __shfl_up(cs, off);
+                if (lane >= off) {
+                    pm = max(pm, t);
+                    cs += u;
                 }
             }
-            const int f = (int)(w.key >> 32);
-            const uint32_t kid = lkid[w.ent];
-            const MultiInfo *mi = w.j >= 0 ? &multi[w.j] : nullptr;
-            if (!mi) {   // a partition's leader
-                const int p = lwho[w.ent];
-                if (ub[p] >= 0) {   // its partition was touched: it is passed over, with what it can still have
-                    bound = max(bound, min(f, ub[p]));
-                    continue;
-                }
-            } else {
-                if (mi->overflow) break;   // the fast path cannot judge this word: nothing behind it is safe
-                bool need = false, bad = false;
-                for (int x = 0; x < mi->n_all; ++x) need = need || tcount[mi->all_part[x]] != w.seen[x];
-                if (need) {
-                    for (int x = 0; x < mi->n_all && !bad; ++x) {
-                        const int p = mi->all_part[x];
-                        if (tcount[p] == w.seen[x]) continue;
-                        int xl = -1;
-                        for (int y = 0; y < mi->n_live; ++y)
-                            if (mi->live_part[y] == p) xl = y;
-                        if (xl >= 0 && w.cnt[xl] > 0) {
-                            // live postings in a touched partition: exact only for a few of them against the partition's leader
-                            if (mi->live_cnt[xl] > kMinorSegs || tcount[p] != 1 || w.seen[x] != 0 || who[p] == kByMulti ||
-                                who[p] != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull) || !hit_known[w.j]) {
-                                bad = true;
-                                break;
-                            }
-                            const unsigned hits = (hitmask[w.j] >> (4 * xl)) & ((1u << mi->live_cnt[xl]) - 1u);
-                            w.rem &= ~(hits << (4 * xl));
-                            w.cnt[xl] -= (int)__popc(hits);
-                        }
-                        w.seen[x] = tcount[p];
-                    }
-                    if (bad) {   // passed over with what it can still have
-                        int still = 0;
-                        for (int y = 0; y < mi->n_live; ++y) {
-                            const int u = ub[mi->live_part[y]];
-                            still += u >= 0 ? min(w.cnt[y], u) : w.cnt[y];
-                        }
-                        bound = max(bound, still);
-                        continue;
-                    }
-                    // its key as of now: the live partitions in first-seen order, the coverage as this iteration leaves it
-                    int total = 0, ord[kMultiParts], no = 0;
-                    uint32_t fs[kMultiParts];
-                    for (int y = 0; y < mi->n_live; ++y) {
-                        if (w.cnt[y] <= 0) continue;
-                        total += w.cnt[y];
-                        uint32_t f0 = mi->first_seg[y];
-                        if (mi->live_cnt[y] <= kMinorSegs) {
-                            const unsigned left = (w.rem >> (4 * y)) & 0xfu;
-                            f0 = mi->seg[y][__ffs((int)left) - 1];
-                        }
-                        int at = no++;
-                        while (at > 0 && fs[at - 1] > f0) {
-                            fs[at] = fs[at - 1];
-                            ord[at] = ord[at - 1];
-                            --at;
-                        }
-                        fs[at] = f0;
-                        ord[at] = y;
-                    }
-                    float acc = 0.0f;
-                    for (int q = 0; q < no; ++q) {
-                        const int p = mi->live_part[ord[q]];
-                        acc += 1.0f / ((float)(coverage[p] + (uint32_t)cov_add[p]) + 1.0f);
-                    }
-                    w.key = ((unsigned long long)(unsigned)total << 32) | (unsigned long long)__float_as_uint(acc);
-                    if (total >= theta) {
-                        if (npend < kMaxPend) pend[npend++] = w;
-                        else bound = max(bound, total);
-                    }
-                    continue;   // (below theta: behind everything this list may yield)
-                }
-            }
-            if (f <= bound) break;   // something passed over or left behind may be ahead: the next iteration decides
-            if (n_win >= max_iter || stop_next) {   // main.rs:344: the loop head
-                stop_now = 1;
-                break;
-            }
-            if (f <= 1) {   // main.rs:353-366 (cannot happen: f >= theta >= 2)
-                stop_now = 1;
-                break;
-            }
-            out_key[n_win] = ukeys[kid];
-            out_freq[n_win] = (uint32_t)f;
-            // trace: iteration (fast + general + 1) << 8 | 1 leader, 2 several-partition word, 3 the same after a re-computed key
-            out_trace[n_win] = ((uint32_t)(st->it_fast + st->it_general + 1) << 8) | (mi ? (from_pend ? 3u : 2u) : 1u);
-            ++n_win;
-            ps->kid[np] = kid;
-            ps->cum[np] = chunks;
-            chunks += (post_off[kid + 1] - post_off[kid] + 63u) / 64u;
-            ++np;
-            if (f < min_freq) stop_next = 1;   // main.rs:387-390: stop after the push
-            if (mi) {
-                // partitions it only has covered segments in lose nothing, but their coverage goes up
-                for (int x = 0; x < mi->n_all; ++x) {
-                    const int p = mi->all_part[x];
-                    if (ub[p] < 0) ub[p] = live_part[p];
-                    who[p] = kByMulti;
-                    tcount[p] = (unsigned char)min(255, tcount[p] + 1);
-                    cov_add[p] += 1;
-                    bump[nb++] = (unsigned short)p;
-                }
-                for (int y = 0; y < mi->n_live; ++y)
-                    if (w.cnt[y] > 0) ub[mi->live_part[y]] -= w.cnt[y];
-                // what a word living in one of these partitions can still have: no more than the partition has left,
-                // and no more than it had (its partition's leader's count, or less than theta if it is not on the list)
-                for (int x = 0; x < mi->n_all; ++x) {
-                    const int p = mi->all_part[x];
-                    bound = max(bound, min(ub[p], max((int)(lead[p] >> 32), theta - 1)));
-                }
-            } else {
-                const int p = lwho[w.ent];
-                ub[p] = live_part[p] - f;   // live segments p keeps (what a several-partition word's postings there are measured against)
+            int before = __shfl_up(pm, 1);   // the bound entry r meets
+            before = lane == 0 ? bound0 : max(bound0, before);
+            const int a_idx = (int)__popcll(fresh_m & below);   // fresh leaders ahead of this lane: all accepted, if it gets that far
+            // main.rs:387-390: a winner below min_freq is the last one
+            const unsigned long long low_m = __ballot(fresh && f < min_freq);
+            const bool sn = sn0 || (low_m & below) != 0ull;
+            const bool ends = fresh && f <= before;   // something passed over or left behind may be ahead: the next iteration decides
+            const bool hands = fresh && !ends && (f <= 1 || nwin0 + a_idx >= max_iter || sn || np0 + a_idx >= kMaxPick);
+            const unsigned long long stop_m = __ballot(ends || hands);
+            const int s_lane = stop_m ? __ffsll((long long)stop_m) - 1 : 64;   // everything before it is settled
+            const int n_set = min(s_lane, n_lead);
+            if (fresh && lane < n_set) {
+                out_key[nwin0 + a_idx] = ent_word[i];
+                out_freq[nwin0 + a_idx] = (uint32_t)f;
+                out_trace[nwin0 + a_idx] = (it_now << 8) | 1u;
+                ps->kid[np0 + a_idx] = kid;
+                ps->cum[np0 + a_idx] = chunks0 + cs - ch;
+                ub[p] = lp_s[p] - f;
                 who[p] = kid;
                 tcount[p] = 1;
                 cov_add[p] += 1;
-                // what a word living in p alone can still have: no more than that, and no more than p's runner-up had
-                // (a word that is not on the list has less than theta)
-                bound = max(bound, min(ub[p], max(second[p], theta - 1)));
-                bump[nb++] = (unsigned short)p;
+                bump[nb0 + a_idx] = (unsigned short)p;
+            }
+            const unsigned long long acc_m = fresh_m & (n_set >= 64 ? ~0ull : (1ull << n_set) - 1ull);
+            const int n_acc = (int)__popcll(acc_m);
+            const int last_lane = acc_m ? 63 - __clzll((long long)acc_m) : 0;
+            const uint32_t last_kid = __shfl(kid, last_lane);
+            const int pm_set = __shfl(pm, max(n_set, 1) - 1);
+            const unsigned cs_set = __shfl(cs, max(n_set, 1) - 1);
+            const bool ends_s = __shfl(ends ? 1 : 0, s_lane & 63) != 0;
+            if (lane == 0) {
+                ws_r = r0 + n_set;
+                ws_np = np0 + n_acc;
+                ws_nb = nb0 + n_acc;
+                ws_nwin = nwin0 + n_acc;
+                ws_bound = n_set ? max(bound0, pm_set) : bound0;
+                ws_chunks = chunks0 + (n_set ? cs_set : 0u);
+                ws_stop_next = sn0 || (low_m & acc_m) != 0ull;
+                if (n_acc) ws_last = last_kid;
+                if (s_lane < n_lead && ends_s) ws_done = 1;
             }
         }
+        __syncthreads();
+        if (tid == 0 && !ws_done) {
+            int n_win = ws_nwin, np = ws_np, nb = ws_nb, stop_next = ws_stop_next, stop_now = 0, bound = ws_bound;
+            unsigned chunks = ws_chunks;
+            uint32_t last_kid = ws_last;
+            WalkWord *pend = walk_s;
+            WalkWord &w = walk_s[kMaxPend];
+            int r = ws_r;
+            bool handed = false, first = true;
+            while (np < kMaxPick) {
+                // a leader next and no word waiting: wave 0's turn again (after at least one entry of this turn)
+                if (!first && npend == 0 && r < limit && !(lwho[top[r]] & 0x8000u)) {
+                    handed = true;
+                    break;
+                }
+                first = false;
+                // the next entry of the order: the list's, or a waiting word whose new key is ahead of it
+                int pk = -1;
+                for (int q = 0; q < npend; ++q)
+                    if (pk < 0 || pend[q].key > pend[pk].key ||
+                        (pend[q].key == pend[pk].key && lkid[pend[q].ent] < lkid[pend[pk].ent]))
+                        pk = q;
+                const int mi_i = r < limit ? top[r] : -1;
+                if (pk < 0 && mi_i < 0) break;
+                bool from_pend = mi_i < 0;
+                if (pk >= 0 && mi_i >= 0)
+                    from_pend = pend[pk].key > lkey[mi_i] || (pend[pk].key == lkey[mi_i] && lkid[pend[pk].ent] < lkid[mi_i]);
+                if (from_pend) {
+                    w = pend[pk];
+                    pend[pk] = pend[--npend];
+                } else {
+                    ++r;
+                    w.ent = mi_i;
+                    w.key = lkey[mi_i];
+                    w.j = (lwho[mi_i] & 0x8000u) ? (int)(lwho[mi_i] & 0x7fffu) : -1;
+                    w.rem = 0xffffu;
+                    if (w.j >= 0) {
+                        const MultiInfo *m0 = mi_slot[w.j] != 0xff ? &mi_s[mi_slot[w.j]] : &multi[w.j];
+                        for (int x = 0; x < kMultiParts; ++x) {
+                            w.cnt[x] = m0->live_cnt[x];
+                            w.seen[x] = 0;
+                        }
+                    }
+                }
+                const int f = (int)(w.key >> 32), ent = w.ent, wj = w.j;
+                const uint32_t kid = lkid[ent];
+                const MultiInfo *mi = wj >= 0 ? (mi_slot[wj] != 0xff ? &mi_s[mi_slot[wj]] : &multi[wj]) : nullptr;
+    #ifdef FAST_CLOCK
+                atomicAdd(&g_fast_clock[8], 1ull);
+                if (mi) atomicAdd(&g_fast_clock[9], 1ull);
+                if (from_pend) atomicAdd(&g_fast_clock[10], 1ull);
+    #endif
+                if (!mi) {   // a partition's leader
+                    const int p = lwho[ent];
+                    if (ub[p] >= 0) {   // its partition was touched: it is passed over, with what it can still have
+                        bound = max(bound, min(f, ub[p]));
+                        continue;
+                    }
+                } else {
+                    if (mi->overflow) break;   // the fast path cannot judge this word: nothing behind it is safe
+                    bool need = false, bad = false;
+                    for (int x = 0; x < mi->n_all; ++x) need = need || tcount[mi->all_part[x]] != w.seen[x];
+                    if (need) {
+                        for (int x = 0; x < mi->n_all && !bad; ++x) {
+                            const int p = mi->all_part[x];
+                            if (tcount[p] == w.seen[x]) continue;
+                            int xl = -1;
+                            for (int y = 0; y < mi->n_live; ++y)
+                                if (mi->live_part[y] == p) xl = y;
+                            if (xl >= 0 && w.cnt[xl] > 0) {
+                                // live postings in a touched partition: exact only for a few of them against the partition's leader
+                                if (mi->live_cnt[xl] > kMinorSegs || tcount[p] != 1 || w.seen[x] != 0 || who[p] == kByMulti ||
+                                    who[p] != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull) || !hit_known[wj]) {
+                                    bad = true;
+                                    break;
+                                }
+                                const unsigned hits = (hitmask[wj] >> (4 * xl)) & ((1u << mi->live_cnt[xl]) - 1u);
+                                w.rem &= ~(hits << (4 * xl));
+                                w.cnt[xl] -= (int)__popc(hits);
+                            }
+                            w.seen[x] = tcount[p];
+                        }
+                        if (bad) {   // passed over with what it can still have
+                            int still = 0;
+                            for (int y = 0; y < mi->n_live; ++y) {
+                                const int u = ub[mi->live_part[y]];
+                                still += u >= 0 ? min(w.cnt[y], u) : w.cnt[y];
+                            }
+                            bound = max(bound, still);
+                            continue;
+                        }
+                        // its key as of now: the live partitions in first-seen order, the coverage as this iteration leaves it
+                        int total = 0, ord[kMultiParts], no = 0;
+                        uint32_t fs[kMultiParts];
+                        for (int y = 0; y < mi->n_live; ++y) {
+                            if (w.cnt[y] <= 0) continue;
+                            total += w.cnt[y];
+                            uint32_t f0 = mi->first_seg[y];
+                            if (mi->live_cnt[y] <= kMinorSegs) {
+                                const unsigned left = (w.rem >> (4 * y)) & 0xfu;
+                                f0 = mi->seg[y][__ffs((int)left) - 1];
+                            }
+                            int at = no++;
+                            while (at > 0 && fs[at - 1] > f0) {
+                                fs[at] = fs[at - 1];
+                                ord[at] = ord[at - 1];
+                                --at;
+                            }
+                            fs[at] = f0;
+                            ord[at] = y;
+                        }
+                        float acc = 0.0f;
+                        for (int q = 0; q < no; ++q) {
+                            const int p = mi->live_part[ord[q]];
+                            acc += 1.0f / ((float)(coverage[p] + (uint32_t)cov_add[p]) + 1.0f);
+                        }
+                        w.key = ((unsigned long long)(unsigned)total << 32) | (unsigned long long)__float_as_uint(acc);
+                        if (total >= theta) {
+                            if (npend < kMaxPend) pend[npend++] = w;
+                            else bound = max(bound, total);
+                        }
+                        continue;   // (below theta: behind everything this list may yield)
+                    }
+                }
+                if (f <= bound) break;   // something passed over or left behind may be ahead: the next iteration decides
+                if (n_win >= max_iter || stop_next) {   // main.rs:344: the loop head
+                    stop_now = 1;
+                    break;
+                }
+                if (f <= 1) {   // main.rs:353-366 (cannot happen: f >= theta >= 2)
+                    stop_now = 1;
+                    break;
+                }
+                out_key[n_win] = ent_word[ent];
+                out_freq[n_win] = (uint32_t)f;
+                // trace: iteration (fast + general + 1) << 8 | 1 leader, 2 several-partition word, 3 the same after a re-computed key
+                out_trace[n_win] = (it_now << 8) | (mi ? (from_pend ? 3u : 2u) : 1u);
+                ++n_win;
+                ps->kid[np] = kid;
+                ps->cum[np] = chunks;
+                chunks += ent_chunks[ent];
+                last_kid = kid;
+                ++np;
+                if (f < min_freq) stop_next = 1;   // main.rs:387-390: stop after the push
+                if (mi) {
+                    // partitions it only has covered segments in lose nothing, but their coverage goes up
+                    for (int x = 0; x < mi->n_all; ++x) {
+                        const int p = mi->all_part[x];
+                        if (ub[p] < 0) ub[p] = lp_s[p];
+                        who[p] = kByMulti;
+                        tcount[p] = (unsigned char)min(255, tcount[p] + 1);
+                        cov_add[p] += 1;
+                        bump[nb++] = (unsigned short)p;
+                    }
+                    for (int y = 0; y < mi->n_live; ++y)
+                        if (w.cnt[y] > 0) ub[mi->live_part[y]] -= w.cnt[y];
+                    // what a word living in one of these partitions can still have: no more than the partition has left,
+                    // and no more than it had (its partition's leader's count, or less than theta if it is not on the list)
+                    for (int x = 0; x < mi->n_all; ++x) {
+                        const int p = mi->all_part[x];
+                        bound = max(bound, min(ub[p], max((int)(lead[p] >> 32), theta - 1)));
+                    }
+                } else {
+                    const int p = lwho[ent];
+                    ub[p] = lp_s[p] - f;   // live segments p keeps (what a several-partition word's postings there are measured against)
+                    who[p] = kid;
+                    tcount[p] = 1;
+                    cov_add[p] += 1;
+                    // what a word living in p alone can still have: no more than that, and no more than p's runner-up had
+                    // (a word that is not on the list has less than theta)
+                    bound = max(bound, min(ub[p], max(second[p], theta - 1)));
+                    bump[nb++] = (unsigned short)p;
+                }
+            }
+            ws_r = r;
+            ws_np = np;
+            ws_nb = nb;
+            ws_nwin = n_win;
+            ws_bound = bound;
+            ws_chunks = chunks;
+            ws_stop_next = stop_next;
+            ws_last = last_kid;
+            if (stop_now) ws_stop_now = 1;
+            if (!handed) ws_done = 1;
+        }
+        __syncthreads();
+        const int done = ws_done;
+        __syncthreads();   // (wave 0 writes the state again in its next turn)
+        if (done) break;
+    }
+    if (tid == 0) {
+        const int n_win = ws_nwin, np = ws_np, nb = ws_nb, stop_next = ws_stop_next, stop_now = ws_stop_now;
+        const unsigned chunks = ws_chunks;
+        const uint32_t last_kid = ws_last;
         ps->cum[np] = chunks;
         ps->n_pick = (unsigned)np;
         ps->n_chunks = chunks;
         st->n_win = n_win;
         st->stop_next = stop_next;
         if (stop_now) st->stop = 1;
-        if (np) st->winner = (int)ps->kid[np - 1];
+        if (np) st->winner = (int)last_kid;
         st->maxf = 0;
         if (np == 0 && !stop_now) {   // left to k_score / k_prefix
             ps->fast_done = 0;
@@ -1258,6 +1454,7 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         n_bump = nb;
     }
     __syncthreads();
+    FCLK(6);
     if (tid < n_bump) atomicAdd(&coverage[bump[tid]], 1u);   // main.rs:371-378: once per partition of a winner's posting list
 }
 
@@ -1654,10 +1851,12 @@ __device__ __forceinline__ void cover_wave(uint32_t row, bool ok, int per, int G
 // within kProbeMax steps (a table fuller than it should ever be) sends its update to memory directly.
 constexpr int kCoverTbl = 4096;    // entries (32 KB): a block's 1,024 segments x ~40 window positions hold ~1,000 distinct words
 constexpr int kProbeMax = 32;
+constexpr unsigned kCoverHeavy = 128;   // work items (of 16 chunks) from which an iteration counts as heavy
 
 __device__ __forceinline__ void table_sub(int32_t *tkey, int32_t *tval, int32_t kid, int n, int32_t *count)
 {
     unsigned h = ((unsigned)kid * 2654435761u) >> 20;
+#pragma unroll 1
     for (int step = 0; step < kProbeMax; ++step) {
         const int32_t old = atomicCAS(&tkey[h], -1, kid);
         if (old == -1 || old == kid) {
@@ -1669,10 +1868,15 @@ __device__ __forceinline__ void table_sub(int32_t *tkey, int32_t *tval, int32_t 
     atomicSub(&count[kid], n);
 }
 
+// `heavy`: an iteration with thousands of chunks, where the variants' updates go through the table as well (their
+// global atomics were half the kernel's time there); in a light one they go to memory directly, fire and forget --
+// a table update is a compare-and-swap the lane waits for, one LDS round trip per window position, and a late
+// iteration has nothing else to hide it behind.  The consensus words of a round of window positions are handed to
+// the lanes, one position each, so that their table updates are ONE round trip, not one per position.
 __device__ __forceinline__ void cover_wave_table(uint32_t row, bool ok, int per, int G, const int32_t *kid_of_inst,
-                                                 int32_t *count, int32_t *tkey, int32_t *tval)
+                                                 int32_t *count, int32_t *tkey, int32_t *tval, bool heavy)
 {
-    constexpr int kDeep = 8;
+    constexpr int kDeep = 20;   // window positions whose loads are in flight together (a 50-base window of 13-mers: two rounds)
     const int lane = threadIdx.x & 63;
     const uint32_t part = ok ? row / (uint32_t)G : 0u;
     const int32_t *col = kid_of_inst + ((size_t)part * per) * G + (ok ? row - part * (uint32_t)G : 0u);
@@ -1680,18 +1884,31 @@ __device__ __forceinline__ void cover_wave_table(uint32_t row, bool ok, int per,
         int32_t v[kDeep];
 #pragma unroll
         for (int j = 0; j < kDeep; ++j) v[j] = (ok && q0 + j < per) ? col[(size_t)(q0 + j) * G] : -1;
+        int32_t my_kid = -1;
+        int my_n = 0;
 #pragma unroll
         for (int j = 0; j < kDeep; ++j) {
             const int32_t k2 = v[j];
-            unsigned long long mk = __ballot(k2 >= 0);
-            if (mk) {   // the window position's most likely word: one update for all its lanes
+            const unsigned long long mk = __ballot(k2 >= 0);
+            if (mk) {   // the window position's most likely word: one update for all its lanes (lane j's, below)
                 const int l = __ffsll((long long)mk) - 1;
                 const int32_t kl = __builtin_amdgcn_readlane(k2, l);
                 const unsigned long long same = __ballot(k2 == kl);
-                if (lane == l) table_sub(tkey, tval, kl, (int)__popcll(same), count);
-                mk &= ~same;
+                if (lane == j) {
+                    my_kid = kl;
+                    my_n = (int)__popcll(same);
+                }
+                if (k2 == kl) v[j] = -1;   // settled
             }
-            if ((mk >> lane) & 1ull) table_sub(tkey, tval, k2, 1, count);
+        }
+        if (my_kid >= 0) table_sub(tkey, tval, my_kid, my_n, count);
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) {   // the variants
+            const int32_t k2 = v[j];
+            if (k2 >= 0) {
+                if (heavy) table_sub(tkey, tval, k2, 1, count);
+                else atomicSub(&count[k2], 1);
+            }
         }
     }
 }
@@ -1784,26 +2001,39 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
     constexpr unsigned kSpan = 16;   // chunks per work item: one per wave
     __shared__ int32_t tkey[kCoverTbl], tval[kCoverTbl];
     __shared__ uint32_t cum_s[kMaxPick + 1], kid_s[kMaxPick], span_s[kMaxPick + 1];
+#ifdef FAST_CLOCK
+    unsigned long long t_prev = wall_clock64();
+#define CCLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (i == 11 || span_s[np < 64 ? np : 64] <= 32u)) { if (i == 15) atomicAdd(&g_fast_clock[7], 1ull); const unsigned long long t_ = wall_clock64(); atomicAdd(&g_fast_clock[i], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define CCLK(i) do { } while (0)
+#endif
     const unsigned np = ps->n_pick;
     if (np == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((unsigned)tid <= np) cum_s[tid] = ps->cum[tid];
-    if ((unsigned)tid < np) kid_s[tid] = ps->kid[tid];
+    if (wave == 0) {   // np <= 64: the winners' spans and their running sum in one wave
+        const unsigned c0 = (unsigned)lane <= np ? ps->cum[lane] : 0u;
+        const unsigned c1 = (unsigned)lane < np ? ps->cum[lane + 1] : 0u;
+        const unsigned mine = (unsigned)lane < np ? (c1 - c0 + kSpan - 1) / kSpan : 0u;
+        unsigned acc = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(acc, off);
+            if (lane >= off) acc += t;
+        }
+        cum_s[lane] = c0;
+        if (lane == 63 && np == 64) cum_s[64] = c1;
+        span_s[lane] = acc - mine;
+        if (lane == 63) span_s[64] = acc;
+        if ((unsigned)lane < np) kid_s[lane] = ps->kid[lane];
+    }
+    __syncthreads();
+    const unsigned total = span_s[np < 64 ? np : 64];
+    CCLK(11);
+    if (blockIdx.x >= total) return;   // block-uniform: most blocks of a late iteration
     for (int e = tid; e < kCoverTbl; e += 1024) {
         tkey[e] = -1;
         tval[e] = 0;
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned acc = 0;
-        for (unsigned j = 0; j < np; ++j) {
-            span_s[j] = acc;
-            acc += (cum_s[j + 1] - cum_s[j] + kSpan - 1) / kSpan;
-        }
-        span_s[np] = acc;
-    }
-    __syncthreads();
-    const unsigned total = span_s[np];
     for (unsigned item = blockIdx.x; item < total; item += gridDim.x) {   // block-uniform
         unsigned lo = 0, hi = np;   // the winner this span belongs to: the last j with span[j] <= item
         while (hi - lo > 1) {
@@ -1817,11 +2047,12 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
             const uint32_t i = post_off[kid] + chunk * 64u + lane, e = post_off[kid + 1];
             uint32_t row = 0;
             int part = -1;
-            bool live = false;
+            bool live = false, mk = false;
             if (i < e) {
                 const uint32_t seg = post[i];
                 part = (int)(seg % (uint32_t)P);
                 row = (uint32_t)part * (uint32_t)G + seg / (uint32_t)P;
+                mk = marked[row] != 0;   // (issued with the claim, not behind it)
                 // Two winners of one iteration may share a segment that is still live: a several-partition word
                 // accepted with a re-computed key lists the segments of its minor partition that the partition's
                 // leader takes as well.  The reference covers it once (the second winner finds it ignored), so the
@@ -1830,10 +2061,13 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
                 const unsigned old = atomicOr(reinterpret_cast<unsigned *>(ignored + (row & ~3u)), 1u << sh8);
                 live = ((old >> sh8) & 0xffu) == 0u;
             }
-            take_live(live_part, live && marked[row], part, lane);
-            if (__ballot(live)) cover_wave_table(row, live, per, G, kid_of_inst, count, tkey, tval);
+            CCLK(12);
+            take_live(live_part, live && mk, part, lane);
+            if (__ballot(live)) cover_wave_table(row, live, per, G, kid_of_inst, count, tkey, tval, total >= kCoverHeavy);
         }
+        CCLK(13);
         __syncthreads();
+        CCLK(14);
         for (int e = tid; e < kCoverTbl; e += 1024) {   // the table goes to memory and is empty again
             const int32_t k = tkey[e];
             if (k >= 0) {
@@ -1843,6 +2077,7 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
             }
         }
         __syncthreads();
+        CCLK(15);
     }
 }
 
@@ -2269,3 +2504,10 @@ int KmerStage::coverage(const SeqView &d_seqs, int n_seq, size_t seq_len, const 
 }
 
 }  // namespace msspe
+
+#ifdef FAST_CLOCK
+extern "C" int msspe_debug_fast_clock(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(msspe::g_fast_clock), sizeof(msspe::g_fast_clock));
+}
+#endif
