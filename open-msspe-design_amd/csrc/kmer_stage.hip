@@ -25,9 +25,24 @@
 
 #include <cstddef>
 
+#include <rocprim/detail/various.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+// rocPRIM's radix sort copies its input to scratch when the pass count is odd and "the input may alias the output",
+// which it assumes of every iterator that is not a pointer (360 MB, 80 us at 45 M instances).  The values here come
+// from a counting iterator, which aliases nothing: say so, ahead of the sort's definition (its call is qualified).
+BEGIN_ROCPRIM_NAMESPACE
+namespace detail
+{
+template <class V>
+inline bool can_iterators_alias(::rocprim::counting_iterator<V>, V *, const size_t)
+{
+    return false;
+}
+}  // namespace detail
+END_ROCPRIM_NAMESPACE
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/functional.hpp>
 
 namespace msspe {
@@ -196,18 +211,22 @@ __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t 
     }
 }
 
+// 1 at the first instance of every word of the sorted key array (the sentinel's run has none): what the scan sums
+// to number the words, read through a transform iterator -- the flags are never stored
 template <class Key>
-__global__ void k_heads(const Key *key, size_t n, uint64_t sentinel, uint32_t *head)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = key[i];
-    head[i] = (k != sentinel && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
-}
+struct HeadOf {
+    const Key *key;
+    uint64_t sentinel;
+    __host__ __device__ uint32_t operator()(uint32_t i) const
+    {
+        const uint64_t k = key[i];
+        return (k != sentinel && (i == 0 || (uint64_t)key[i - 1] != k)) ? 1u : 0u;
+    }
+};
 
 template <class Key>
-__global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *head,
-                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G,
+__global__ void k_index(const Key *key, const uint32_t *val,
+                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G, int M,
                         int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys,
                         uint16_t *word_part, uint8_t *word_multi)
 {
@@ -217,33 +236,24 @@ __global__ void k_index(const Key *key, const uint32_t *val, const uint32_t *hea
     const uint32_t inst = val[i];
     const uint32_t seg = inst / (uint32_t)per, q = inst % (uint32_t)per;
     const size_t slot = ((size_t)(seg % (uint32_t)P) * per + q) * (uint32_t)G + seg / (uint32_t)P;   // inst_slot of its row
+    // post_off[M] = number of non-sentinel instances (sentinels sort last)
     if (k == sentinel) {
         kid_of_inst[slot] = -1;
+        if (i == 0 || (uint64_t)key[i - 1] != sentinel) post_off[M] = (uint32_t)i;
         return;
     }
-    const uint32_t kid = hscan[i] + head[i] - 1;
+    if (i == n - 1) post_off[M] = (uint32_t)n;
+    const bool first = i == 0 || (uint64_t)key[i - 1] != k;   // HeadOf
+    const uint32_t kid = hscan[i] + (first ? 1u : 0u) - 1;
     kid_of_inst[slot] = (int32_t)kid;
     post[i] = seg;
-    if (head[i]) {
+    if (first) {
         post_off[kid] = (uint32_t)i;
         ukeys[kid] = k;
         word_part[kid] = (uint16_t)(seg % (uint32_t)P);   // the partition of the word's first posting ...
     } else if ((val[i - 1] / (uint32_t)per) % (uint32_t)P != seg % (uint32_t)P) {
         word_multi[kid] = 1;   // ... and whether any two neighbouring postings differ in theirs (cleared by the host)
     }
-}
-
-// lower bound of the sentinel in the sorted key array (single thread, log n steps)
-template <class Key>
-__global__ void k_tail(const Key *key, size_t n, uint64_t sentinel, uint32_t *post_off, int M)
-{
-    size_t lo = 0, hi = n;
-    while (lo < hi) {
-        const size_t mid = (lo + hi) / 2;
-        if (key[mid] < sentinel) lo = mid + 1;
-        else hi = mid;
-    }
-    post_off[M] = (uint32_t)lo;
 }
 
 __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
@@ -2220,12 +2230,12 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     const size_t n_inst = (size_t)n_seg * per;
     const uint64_t sentinel = 1ull << (2 * k);
     int rc;
-    // buffers: 0/1 keys, 2/3 vals, 4 head, 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
+    // buffers: 0/1 keys, 2/3 vals, 4 (unused), 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
     // 10 count+tied, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp, 16 the candidate-list loop's
     // PickState + per-word results (key, id, two partition bitmaps)
     if ((rc = ensure(0, n_inst * 8, err)) || (rc = ensure(1, n_inst * 8, err)) ||
         (rc = ensure(3, n_inst * 4, err)) ||
-        (rc = ensure(4, n_inst * 4, err)) || (rc = ensure(5, n_inst * 4, err)) ||
+        (rc = ensure(5, n_inst * 4, err)) ||
         (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
         (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, ((size_t)n_seg + 7) & ~(size_t)3, err)) ||
@@ -2239,7 +2249,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     if ((rc = ensure(16, pick_bytes + res_bytes + multi_bytes + (size_t)kMaxMulti * 4, err))) return rc;
     uint64_t *key_a = (uint64_t *)buf_[0], *key_b = (uint64_t *)buf_[1];
     uint32_t *val_b = (uint32_t *)buf_[3];
-    uint32_t *head = (uint32_t *)buf_[4], *hscan = (uint32_t *)buf_[5];
+    uint32_t *hscan = (uint32_t *)buf_[5];
     int32_t *kid_of_inst = (int32_t *)buf_[6];
     uint32_t *post = (uint32_t *)buf_[7], *post_off = (uint32_t *)buf_[8];
     uint64_t *ukeys = (uint64_t *)buf_[9];
@@ -2287,20 +2297,30 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         // not stored anywhere before the sort: a counting iterator supplies them
         const rocprim::counting_iterator<uint32_t> val_a(0u);
         size_t tmp_bytes = 0, tmp2 = 0;
-        KM_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u,
-                                         (unsigned)(2 * k + 1), stream));
-        KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
+        // 9 bits per pass where that saves a pass (13-mers: 27 key bits, three passes instead of four)
+        using Sort9 = rocprim::radix_sort_config<
+            rocprim::default_config, rocprim::default_config,
+            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
+                                                rocprim::block_radix_rank_algorithm::match>>;
+        const unsigned key_bits = (unsigned)(2 * k + 1);
+        const bool nine = (key_bits + 8) / 9 < (key_bits + 7) / 8;
+        KM_TRY(nine ? rocprim::radix_sort_pairs<Sort9>(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream)
+                    : rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream));
+        const auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), HeadOf<Key>{kb, sentinel});
+        KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, heads, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
         int rc2;
         if ((rc2 = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc2;
-        KM_TRY(rocprim::radix_sort_pairs(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u,
-                                         (unsigned)(2 * k + 1), stream));
+        KM_TRY(nine ? rocprim::radix_sort_pairs<Sort9>(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream)
+                    : rocprim::radix_sort_pairs(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream));
         const int g_inst = (int)((n_inst + 255) / 256);
-        hipLaunchKernelGGL(k_heads<Key>, dim3(g_inst), dim3(256), 0, stream, kb, n_inst, sentinel, head);
-        KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, head, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
+        KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, heads, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
         uint32_t last_head = 0, last_scan = 0;
-        KM_TRY(hipMemcpyAsync(&last_head, head + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+        Key last_keys[2] = {};   // the last instance's head flag, from the last two keys
+        const size_t n_last = n_inst >= 2 ? 2 : 1;
+        KM_TRY(hipMemcpyAsync(last_keys, kb + n_inst - n_last, sizeof(Key) * n_last, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
+        last_head = ((uint64_t)last_keys[n_last - 1] != sentinel && (n_last == 1 || last_keys[0] != last_keys[1])) ? 1u : 0u;
         M = (int)(last_head + last_scan);
         if (M == 0) return MSSPE_OK;
         // number of valid instances = first sentinel position: post_off[M]
@@ -2314,10 +2334,8 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         KM_TRY(hipMemsetAsync(live_part, 0, lp_bytes + 4 * (size_t)M, stream));   // epoch 0 = on no list
         KM_TRY(hipMemsetAsync(marked, 1, (size_t)n_seg, stream));                  // the first list counts every segment (k_live_all)
         KM_TRY(hipMemsetAsync(word_multi, 0, (size_t)M, stream));
-        hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, head, hscan, n_inst,
-                           sentinel, per, (int)P, n_seq, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
-        // post_off[M] = number of non-sentinel instances (sentinels sort last)
-        hipLaunchKernelGGL(k_tail<Key>, dim3(1), dim3(1), 0, stream, kb, n_inst, sentinel, post_off, M);
+        hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, hscan, n_inst,
+                           sentinel, per, (int)P, n_seq, M, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
         return MSSPE_OK;
     };
     if ((rc = 2 * k + 1 <= 32 ? build_index(uint32_t{}) : build_index(uint64_t{}))) return rc;
