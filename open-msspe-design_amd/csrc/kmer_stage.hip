@@ -256,6 +256,37 @@ __global__ void k_index(const Key *key, const uint32_t *val,
     }
 }
 
+// A run's byte fills in one launch (seven memsets were seven launches, 7 us each with their gaps): job j sets n[j]
+// bytes at p[j] to v[j]; 16-byte stores between the aligned ends, bytes at the ends.
+struct FillJobs {
+    void *p[8];
+    size_t n[8];
+    unsigned char v[8];
+    int count;
+};
+__global__ void __launch_bounds__(256) k_fill_jobs(FillJobs jobs)
+{
+    for (int j = 0; j < jobs.count; ++j) {
+        unsigned char *p = (unsigned char *)jobs.p[j];
+        const size_t n = jobs.n[j];
+        const unsigned w = 0x01010101u * jobs.v[j];
+        const uintptr_t a0 = ((uintptr_t)p + 15) & ~(uintptr_t)15, a1 = ((uintptr_t)p + n) & ~(uintptr_t)15;
+        if (a1 <= a0) {   // shorter than one aligned chunk
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = jobs.v[j];
+            continue;
+        }
+        uint4 *body = (uint4 *)a0;
+        const size_t chunks = (a1 - a0) / 16;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (size_t)gridDim.x * 256)
+            body[i] = make_uint4(w, w, w, w);
+        if (blockIdx.x == 0 && threadIdx.x < 32) {
+            const size_t head = a0 - (uintptr_t)p, tail = (uintptr_t)p + n - a1;
+            if (threadIdx.x < 16 && threadIdx.x < head) p[threadIdx.x] = jobs.v[j];
+            if (threadIdx.x >= 16 && threadIdx.x - 16 < tail) ((unsigned char *)a1)[threadIdx.x - 16] = jobs.v[j];
+        }
+    }
+}
+
 __global__ void k_init_counts(const uint32_t *post_off, int M, int32_t *count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2161,8 +2192,18 @@ int KmerStage::ensure(int slot, size_t bytes, std::string &err)
     return MSSPE_OK;
 }
 
+void KmerStage::drop_loop_graph()
+{
+    if (loop_exec_) (void)hipGraphExecDestroy(loop_exec_);
+    if (loop_graph_) (void)hipGraphDestroy(loop_graph_);
+    loop_exec_ = nullptr;
+    loop_graph_ = nullptr;
+    loop_sig_.clear();
+}
+
 void KmerStage::release()
 {
+    drop_loop_graph();
     if (pinned_) (void)hipHostFree(pinned_);
     pinned_ = nullptr;
     for (int s = 0; s < 19; ++s) {
@@ -2331,9 +2372,24 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         live_part = (int32_t *)((char *)buf_[17] + wp_bytes);
         cand_flag = (uint32_t *)((char *)buf_[17] + wp_bytes + lp_bytes);
         marked = (uint8_t *)(cand_flag + M);
-        KM_TRY(hipMemsetAsync(live_part, 0, lp_bytes + 4 * (size_t)M, stream));   // epoch 0 = on no list
-        KM_TRY(hipMemsetAsync(marked, 1, (size_t)n_seg, stream));                  // the first list counts every segment (k_live_all)
-        KM_TRY(hipMemsetAsync(word_multi, 0, (size_t)M, stream));
+        {
+            FillJobs fj{};
+            int nj = 0;
+            auto job = [&](void *ptr, size_t bytes, unsigned char value) {
+                fj.p[nj] = ptr;
+                fj.n[nj] = bytes;
+                fj.v[nj++] = value;
+            };
+            job(live_part, lp_bytes + 4 * (size_t)M, 0);   // live_part, cand_flag: epoch 0 = on no list
+            job(marked, (size_t)n_seg, 1);                  // the first list counts every segment (k_live_all)
+            job(word_multi, (size_t)M, 0);                  // (k_index sets it)
+            job(ignored, (size_t)n_seg, 0);
+            job(coverage, (size_t)P * 8, 0);
+            job(ps, sizeof(PickState), 0);
+            job(out_trace, sizeof(uint32_t) * (size_t)opt.max_iterations, 0);
+            fj.count = nj;
+            hipLaunchKernelGGL(k_fill_jobs, dim3(512), dim3(256), 0, stream, fj);
+        }
         hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, hscan, n_inst,
                            sentinel, per, (int)P, n_seq, M, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
         return MSSPE_OK;
@@ -2341,8 +2397,6 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     if ((rc = 2 * k + 1 <= 32 ? build_index(uint32_t{}) : build_index(uint64_t{}))) return rc;
     if (M == 0) return MSSPE_OK;
     hipLaunchKernelGGL(k_init_counts, dim3((M + 255) / 256), dim3(256), 0, stream, post_off, M, count);
-    KM_TRY(hipMemsetAsync(ignored, 0, (size_t)n_seg, stream));
-    KM_TRY(hipMemsetAsync(coverage, 0, (size_t)P * 8, stream));
     KM_TRY(hipGetLastError());
 
     // 3. greedy loop: one iteration = five launches with constant arguments, captured once into a
@@ -2356,10 +2410,9 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     h0.max_iter = std::min(opt.max_iterations, capacity);
     h0.min_freq = opt.max_mismatch_segments;
     h0.need_rebuild = 1;   // the candidate-list loop starts by making its list
-    KM_TRY(hipMemcpyAsync(st, &h0, sizeof h0, hipMemcpyHostToDevice, stream));
-    KM_TRY(hipMemsetAsync(ps, 0, sizeof(PickState), stream));
-    KM_TRY(hipMemsetAsync(out_trace, 0, sizeof(uint32_t) * (size_t)opt.max_iterations, stream));
-    KM_TRY(hipStreamSynchronize(stream));
+    if (!pinned_) KM_TRY(hipHostMalloc(&pinned_, 256, hipHostMallocDefault));
+    *(Status *)pinned_ = h0;   // (read back into only after this copy, in stream order)
+    KM_TRY(hipMemcpyAsync(st, pinned_, sizeof h0, hipMemcpyHostToDevice, stream));
     auto enqueue_iteration = [&](hipStream_t s_, int /*node*/) {
         hipLaunchKernelGGL(k_max_count<false>, dim3(red_grid), dim3(256), 0, s_, count, M, st, 0, (int32_t *)nullptr, 0);
         hipLaunchKernelGGL(k_collect_tied, dim3((M + 255) / 256), dim3(256), 0, s_, count, M, st,
@@ -2412,7 +2465,10 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     };
     // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration)
     constexpr int kBatch = 32;
-    constexpr int kBatchN = 8;    // candidate-list iterations per graph (an iteration selects up to 64 winners)
+#ifndef MSSPE_BATCHN
+#define MSSPE_BATCHN 8
+#endif
+    constexpr int kBatchN = MSSPE_BATCHN;    // candidate-list iterations per graph (an iteration selects up to 64 winners)
     GraphGuard gg[2];   // 0: five-launch iterations, 1: candidate-list iterations
     bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
     auto capture = [&](int which) -> bool {
@@ -2431,6 +2487,15 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         return ok;
     };
     const bool narrow_ok = narrow_loop_ && P <= kNarrowMaxP;
+    // the candidate-list graph of an earlier run serves this one if every argument enqueue_narrow passes is unchanged
+    const std::vector<uint64_t> narrow_sig = {
+        (uint64_t)(uintptr_t)st, (uint64_t)(uintptr_t)ps, (uint64_t)(uintptr_t)mcand, (uint64_t)(uintptr_t)multi,
+        (uint64_t)(uintptr_t)post_off, (uint64_t)(uintptr_t)post, (uint64_t)(uintptr_t)ignored, (uint64_t)(uintptr_t)count,
+        (uint64_t)(uintptr_t)cand, (uint64_t)(uintptr_t)word_part, (uint64_t)(uintptr_t)word_multi,
+        (uint64_t)(uintptr_t)live_part, (uint64_t)(uintptr_t)coverage, (uint64_t)(uintptr_t)ukeys,
+        (uint64_t)(uintptr_t)kid_of_inst, (uint64_t)(uintptr_t)out_key, (uint64_t)(uintptr_t)out_freq,
+        (uint64_t)(uintptr_t)out_trace, (uint64_t)(uintptr_t)marked, (uint64_t)P, (uint64_t)n_seq, (uint64_t)per};
+    if (loop_exec_ && loop_sig_ != narrow_sig) drop_loop_graph();
     if (!pinned_) KM_TRY(hipHostMalloc(&pinned_, 256, hipHostMallocDefault));
     Status *h_pin = (Status *)pinned_;
     Status h = h0;
@@ -2441,9 +2506,21 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         if (wide_left) --wide_left;
         if (which && h.need_rebuild == 1) enqueue_rebuild(stream);
         if (which && h.want_general && h.need_rebuild != 1) enqueue_general(stream);
-        if (use_graph && !gg[which].exec && !capture(which)) use_graph = false;
+        if (use_graph && which == 1 && !loop_exec_) {
+            if (capture(1)) {   // kept by the stage (drop_loop_graph), not by this call's guard
+                loop_graph_ = gg[1].graph;
+                loop_exec_ = gg[1].exec;
+                gg[1].graph = nullptr;
+                gg[1].exec = nullptr;
+                loop_sig_ = narrow_sig;
+            } else {
+                use_graph = false;
+            }
+        } else if (use_graph && which == 0 && !gg[0].exec && !capture(0)) {
+            use_graph = false;
+        }
         if (use_graph) {
-            KM_TRY(hipGraphLaunch(gg[which].exec, stream));
+            KM_TRY(hipGraphLaunch(which ? loop_exec_ : gg[0].exec, stream));
         } else {
             for (int b = 0; b < (which ? kBatchN : kBatch); ++b) which ? enqueue_narrow(stream, b) : enqueue_iteration(stream, b);
         }
@@ -2472,13 +2549,25 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         return MSSPE_ERR_CAPACITY;
     }
     if (n_win) {
-        std::vector<uint64_t> hk((size_t)n_win);
-        KM_TRY(hipMemcpyAsync(hk.data(), out_key, sizeof(uint64_t) * n_win, hipMemcpyDeviceToHost, stream));
-        KM_TRY(hipMemcpyAsync(freq_out, out_freq, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
         trace_.resize((size_t)n_win);
-        KM_TRY(hipMemcpyAsync(trace_.data(), out_trace, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
-        KM_TRY(hipStreamSynchronize(stream));
-        for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
+        const size_t mi = (size_t)opt.max_iterations, all = 16 * mi;
+        if (all <= (1u << 20)) {
+            // words, frequencies and trace lie one behind the other: one copy (each pageable copy is a host round trip)
+            std::vector<unsigned char> host(all);
+            KM_TRY(hipMemcpyAsync(host.data(), out_key, all, hipMemcpyDeviceToHost, stream));
+            KM_TRY(hipStreamSynchronize(stream));
+            const uint64_t *hk = reinterpret_cast<const uint64_t *>(host.data());
+            for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
+            std::memcpy(freq_out, host.data() + 8 * mi, sizeof(uint32_t) * (size_t)n_win);
+            std::memcpy(trace_.data(), host.data() + 12 * mi, sizeof(uint32_t) * (size_t)n_win);
+        } else {
+            std::vector<uint64_t> hk((size_t)n_win);
+            KM_TRY(hipMemcpyAsync(hk.data(), out_key, sizeof(uint64_t) * n_win, hipMemcpyDeviceToHost, stream));
+            KM_TRY(hipMemcpyAsync(freq_out, out_freq, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
+            KM_TRY(hipMemcpyAsync(trace_.data(), out_trace, sizeof(uint32_t) * n_win, hipMemcpyDeviceToHost, stream));
+            KM_TRY(hipStreamSynchronize(stream));
+            for (int i = 0; i < n_win; ++i) words_out[i] = lex_to_packed(hk[i], k);
+        }
     }
     *n_out = n_win;
     return MSSPE_OK;

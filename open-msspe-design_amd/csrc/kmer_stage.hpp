@@ -61,6 +61,13 @@ private:
     bool narrow_loop_ = true;
     int loop_stats_[4] = {};
     std::vector<uint32_t> trace_;
+    // the candidate-list loop's graph (eight iterations), kept across runs for as long as its kernels' arguments are
+    // what they were (same buffers, same shape: the two directions of one alignment, repeated calls); capturing and
+    // instantiating it costs 0.9 ms
+    hipGraph_t loop_graph_ = nullptr;
+    hipGraphExec_t loop_exec_ = nullptr;
+    std::vector<uint64_t> loop_sig_;
+    void drop_loop_graph();
     int ensure(int slot, size_t bytes, std::string &err);
 };
 
