@@ -4,7 +4,7 @@
 # starts the python interpreter itself (no env/bash wrapper), counters in their own passes.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/profiles_raw
+OUT=gpurun_out/profiles_raw   # (delete the local copy of this directory before the call: gpurun merges, it does not mirror)
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o bench -- python3 bench.py --steps 2 --warmup 1 > $OUT/bench_stdout.log 2>&1 || exit 1
 echo "bench done"
