@@ -354,7 +354,7 @@ def main():
         # position-weighted sum of the merged per-primer counts: equal for every sharding of the same pool
         weights = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
         conflict_checksum = int((d_conf.to(torch.int64) * weights).sum().item())
-        # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^27 checks of this rank's block
+        # dominant kernel: the first-stage all-pairs kernel; one launch covers up to 2^29 checks of this rank's block
         checks_rank = float(shard) * float(n) * args.steps
         per_launch_checks = checks_rank / max(launches, 1)
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)

@@ -44,11 +44,12 @@ struct ChemEntry {
     int wave_max_k = 0;           // f64 one-wave-per-pair kernel (thal_pairs_wave.hip)
 };
 
-constexpr long kChunkPairs = 1L << 27;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26)
+constexpr long kChunkPairs = 1L << 29;       // pairs per launch of the all-pairs kernel (a launch's tail: 2.4 % at 2^24, 1.4 % at 2^26; a 65,536-primer
+                                             // pool: 1850 ms at 2^27, 1822 at 2^29, 1819 at 2^30 -- and a hand-over list of as many entries, 4 GB, twice)
 constexpr int kHairpinLaneFrom = 8192;       // oligos per call from which HAIRPIN_TH runs one lane per oligo (msspe_oligo_stats_dev)
 constexpr long kListCapMin = 1L << 20;       // hand-over list entries (grows with the call up to kListCapMax): one launch can never overrun it
 constexpr long kListCapMax = 1L << 30;       // 8 GB per list (two of them, 6 % of the card's memory): the stages behind the first
-                                             // run every eight launches of 2^27 pairs, so that a list cannot be overrun even if
+                                             // run every two launches of 2^29 pairs, so that a list cannot be overrun even if
                                              // every pair were handed on (2.7 % are); k_accumulate_overflow checks the counters
                                              // against it all the same.  The small kernels of a flush do not fill the card:
                                              // 2^28 -> 2^30 is 17 -> 5 flushes per 65,536^2 screen and 1.5 % of its time
@@ -604,7 +605,7 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     g.wsH = ctx->wsH;
     g.ws_lanes = kGenericLanes;
     // A launch covers at most kChunkPairs pairs, and never more than one hand-over list holds (a fixed
-    // list_cap_log2 below 27, or lists shrunk because the card is short of memory): even a launch that handed
+    // list_cap_log2 below 29, or lists shrunk because the card is short of memory): even a launch that handed
     // every pair on cannot overrun its list.
     const long chunk_pairs = std::min(kChunkPairs, kListCap);
     long rows_per_chunk = chunk_pairs / ncols;
