@@ -174,7 +174,31 @@ def stage_a_line(eng, device):
                 "frac_of_6.29TBps_copy_ceiling": alg_bytes / (ms * 1e-3) / 6.29e12,
                 "note": "host wall time per direction incl. the greedy loop's dependent launches and its host "
                         "round trips; per-kernel times: profiles/r03_stage_a_kernel_stats.csv, DESIGN.md 4.3"})
+    roof = stage_a_kernel_roofline(alg_bytes)
+    if roof:
+        out["roofline"] = roof
     return out
+
+
+def stage_a_kernel_roofline(alg_bytes: float):
+    """bytes / SUM of kernel time per direction, from the committed rocprofv3 summary of the same workload
+    (tools/perf_stage_a.py 10000 30000 under --kernel-trace --stats: two directions x two repetitions; the packing of
+    byte rows, which the packed entry point does not run, and the engine's one-off LDS probe are left out).  Imported,
+    and labelled so: bench.py cannot see kernel times of this many small launches without the profiler."""
+    import csv
+    path = Path(__file__).resolve().parent / "profiles" / "r03_stage_a_kernel_stats.csv"
+    if not path.exists():
+        return None
+    total_ns = 0.0
+    for row in csv.DictReader(open(path)):
+        name = row["Name"]
+        if "k_pack_rows" in name or "k_lds_" in name:
+            continue
+        total_ns += float(row["TotalDurationNs"])
+    ms = total_ns / 4 / 1e6
+    return {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 6290.0, "unit": "GB/s",
+            "frac": alg_bytes / (ms * 1e-3) / 6.29e12, "kernel_ms_per_direction": ms,
+            "source": "profiles/r03_stage_a_kernel_stats.csv (imported: rocprofv3 kernel times of the same workload)"}
 
 
 def stage_b_line(eng, device, cpu_seconds: float):

@@ -330,3 +330,18 @@ def test_packed_alignment_equals_the_ascii_path(eng, m, oracle):
         assert 0 < hit_p.sum() < hit_p.size
     finally:
         assert eng.L.msspe_device_free(eng.ptr, dev) == 0
+
+
+def test_the_loop_graph_is_kept_and_replaced_as_the_arguments_change(eng, m, oracle):
+    """The candidate-list loop's graph outlives a call (kmer_stage.hpp: loop_exec_) and serves the next one if every
+    kernel argument is unchanged -- the two directions of one alignment, a repeated call -- and is captured anew when
+    the shape, the window or the winner capacity changes.  Shapes alternate here so that every call either reuses
+    the graph of the same shape's earlier call or replaces another shape's."""
+    shapes = [(60, 5000, dict()), (90, 3500, dict(win=40)), (60, 5000, dict()), (60, 5000, dict(iters=300)),
+              (90, 3500, dict(win=40)), (25, 5000, dict(k=11))]
+    seen = {}
+    for n_rows, length, kw in shapes:
+        key = (n_rows, length, tuple(sorted(kw.items())))
+        if key not in seen:
+            seen[key] = [bytes(r).decode() for r in m.synth.aligned_genomes(n_rows, length, seed=len(seen) + 3)]
+        run_both(eng, m, oracle, seen[key], **kw)
