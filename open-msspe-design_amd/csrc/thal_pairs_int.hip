@@ -349,6 +349,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
     //      (fillMatrix / maxTM), then the terminal dG as thal() compares it
     double S = 0.0, S_1 = 0.0, Gt_1 = 0.0;
     int H = 0, P = 0, H_1 = 0, P_1 = 0, dpath = 0, dpath_1 = 0, endW = pickW;
+    bool unsettled = false;   // RESOLVE: the two walks were compared, but one of them may not be the walk thal() made
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
@@ -436,12 +437,20 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
                     second = second & !tied_pick_cannot_conflict(K, G0, P - 1, tieLo - ht0, tieHi - ht0);
                     any_second = __builtin_amdgcn_ballot_w64(second) != 0ull;
                 }
-            } else if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
-                S = S_1;
-                H = H_1;
-                P = P_1;
-                dpath = dpath_1;
-                endW = pickW;
+            } else {
+                // The comparison is between the doubles of BOTH walks, and they differ by rounding alone: a walk through a
+                // cell with an equal-valued alternative (or one whose replay missed the tracked enthalpy) may carry other
+                // last bits than the walk thal() made, whichever of the two is kept -- the pick stays open then.
+                // (Found by the pair campaign, seed 301: GCGGCGGCCGCCGC x GCCGGCCGGGCGGG answered 15e-12 cal/mol off,
+                // TCTAGACTAGCCAGCA x TGAAGAAAGCTAAGTC with the other cell's structure.)
+                unsettled = second & ((dpath | dpath_1) != 0);
+                if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
+                    S = S_1;
+                    H = H_1;
+                    P = P_1;
+                    dpath = dpath_1;
+                    endW = pickW;
+                }
             }
         }
     }
@@ -472,7 +481,7 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         }
         // a tied terminal pick: resolved above (list mode, one tie), final as "no conflict" when only decisions
         // are asked for and this one is not close (int_core.hpp kPickMargin), handed on otherwise
-        const bool open_tie = RESOLVE ? (nTie > 1) : (nTie > 0);
+        const bool open_tie = RESOLVE ? (nTie > 1) | unsettled : (nTie > 0);
         const int ht = (H + rH) / 10;
         defer |= (open_tie && !(decisions_only && tied_pick_cannot_conflict(K, G, N, tieLo - ht, tieHi - ht))) ? kDeferPick : 0;
         // a cell of the path with an equal-valued alternative of the same enthalpy: the other path gives the same

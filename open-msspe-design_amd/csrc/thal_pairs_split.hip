@@ -399,13 +399,18 @@ __device__ __forceinline__ SplitResult run_pair_split(SharedS &sh, const ThalCon
             const CellS b = cell_s(q, (endW >> 5) & 31, endW & 31);
             const double rSn = sh.S[b.idxR] + kTiny, rHn = (double)sh.H[b.idxR] + kTiny;
             const double Gt = (((double)H + rHn) + K.init_H) - kT37 * ((S + rSn) + K.init_S);
-            if (pass == 0) Gt_1 = Gt;
-            else if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
-                S = S_1;
-                H = H_1;
-                P = P_1;
-                dpath = dpath_1;
-                endW = pickW;
+            if (pass == 0) {
+                Gt_1 = Gt;
+            } else {
+                // both walks' doubles are compared: a flag on either of them leaves the pick open (thal_pairs_int.hip)
+                if (second & ((dpath | dpath_1) != 0)) defer |= kDeferPick;
+                if (second & !(Gt < Gt_1)) {   // strict: the first cell stays unless the second is lower
+                    S = S_1;
+                    H = H_1;
+                    P = P_1;
+                    dpath = dpath_1;
+                    endW = pickW;
+                }
             }
         }
     }

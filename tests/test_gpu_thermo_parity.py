@@ -119,6 +119,24 @@ def test_other_oligo_lengths(eng, m, oracle, oracle_tables, k):
     check_pool(eng, m, oracle, oracle_tables, pool)
 
 
+@pytest.mark.parametrize("k,oligos,chem_kw,thr", [
+    (14, ["GCGGCGGCCGCCGC", "GCCGGCCGGGCGGG", "GGCCGGCCGGGCGG"], dict(temp_c=37.0), -6000.0),
+    (16, ["TCTAGACTAGCCAGCA", "TGAAGAAAGCTAAGTC"], dict(mv=200.0, dv=0.5, dntp=0.2), -1500.0)])
+def test_a_resolved_pick_whose_walks_meet_a_tie_stays_open(eng, m, oracle, oracle_tables, k, oligos, chem_kw, thr):
+    """Two cells tie in the terminal pick and the list stage settles them by comparing the doubles of both walks
+    (thal_pairs_int.hip RESOLVE, thal_pairs_split.hip): if either walk passes a cell with an equal-valued alternative
+    its last bits need not be thal()'s, so the comparison decides nothing and the pair belongs to the f64 kernels.
+    These pairs came out 15e-12 cal/mol off / with the other cell's structure (pair campaign, seed 301, round 3);
+    all orders of them, among random oligos of the same length."""
+    pool = oligos + m.synth.pool_strings(m.synth.random_pool(150, k, seed=7 * k))
+    for pair_kernel in ("auto", "int"):
+        eng.set_option("pair_kernel", pair_kernel)
+        try:
+            check_pool(eng, m, oracle, oracle_tables, pool, chem_kw, thr)
+        finally:
+            eng.set_option("pair_kernel", "auto")
+
+
 def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
     """primer3_core view (od-msspe/src/primer.rs:143-166): Tm, GC%, SELF_ANY/END, HAIRPIN."""
     pool = m.synth.pool_strings(m.synth.random_pool(300, 13, seed=9))
