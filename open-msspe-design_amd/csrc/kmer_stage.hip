@@ -1042,8 +1042,16 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         const uint32_t kid = cand[i] & ~kCandLong;
         const int c = count[kid];
         m = max(m, c);
-        if (!word_multi[kid] && c > 0)
-            atomicMax(&lead[word_part[kid]], ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(0xffffffffu - kid));
+        if (!word_multi[kid] && c > 0) {
+            // the partition's leader, and its runner-up in the same pass: whichever of the two keys loses this exchange
+            // -- the candidate, or the leader it displaces -- is a word of the partition that is not its leader (the
+            // final leader wins every exchange it is in), and every such word loses exactly one
+            const int p = word_part[kid];
+            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (unsigned long long)(0xffffffffu - kid);
+            const unsigned long long old = atomicMax(&lead[p], key);
+            const int loser = (int)(min(old, key) >> 32);
+            if (loser > 0) atomicMax(&second[p], loser);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if (lane == 0) red[wave] = m;
@@ -1056,15 +1064,9 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         if (tid == 0) st->need_rebuild = 1;
         return;
     }
-    // every partition's runner-up: once the leader is covered nothing that lives in the partition alone can have more than
-    // the runner-up has now (counts only fall), however many live segments the partition keeps -- the bound that still
-    // works late in the loop, when a leader covers a small part of what its partition has left
-    for (unsigned i = (unsigned)tid; i < n_cand; i += 1024) {
-        const uint32_t kid = cand[i] & ~kCandLong;
-        if (word_multi[kid]) continue;
-        const int p = word_part[kid];
-        if (kid != 0xffffffffu - (uint32_t)(lead[p] & 0xffffffffull)) atomicMax(&second[p], count[kid]);
-    }
+    // (second[p], every partition's runner-up: once the leader is covered nothing that lives in the partition alone can
+    // have more than the runner-up has now -- counts only fall -- however many live segments the partition keeps: the
+    // bound that still works late in the loop, when a leader covers a small part of what its partition has left)
     __syncthreads();
     FCLK(2);
     // the entries: leaders with a count of at least theta (nothing below it may be accepted from this list) ...
