@@ -27,7 +27,6 @@
 
 #include <rocprim/detail/various.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 // rocPRIM's radix sort copies its input to scratch when the pass count is odd and "the input may alias the output",
 // which it assumes of every iterator that is not a pointer (360 MB, 80 us at 45 M instances).  The values here come
 // from a counting iterator, which aliases nothing: say so, ahead of the sort's definition (its call is qualified).
@@ -211,27 +210,52 @@ __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t 
     }
 }
 
-// 1 at the first instance of every word of the sorted key array (the sentinel's run has none): what the scan sums
-// to number the words, read through a transform iterator -- the flags are never stored
-template <class Key>
-struct HeadOf {
-    const Key *key;
-    uint64_t sentinel;
-    __host__ __device__ uint32_t operator()(uint32_t i) const
-    {
-        const uint64_t k = key[i];
-        return (k != sentinel && (i == 0 || (uint64_t)key[i - 1] != k)) ? 1u : 0u;
-    }
-};
+// Numbering the words of the sorted key array (a word's number = the first instances before its own): the first
+// instances are counted per block of 256 keys (k_head_count), a small scan turns the 176 k counts into the blocks'
+// bases, and k_index finishes the numbering inside its block with ballots.  (A scan over the 45 M flags, and the
+// flags themselves, cost 0.37 ms more; reading them through a transform iterator 0.25.)
+constexpr int kIndexBlock = 256;
 
 template <class Key>
-__global__ void k_index(const Key *key, const uint32_t *val,
-                        const uint32_t *hscan, size_t n, uint64_t sentinel, int per, int P, int G, int M,
+__device__ __forceinline__ bool first_instance(const Key *key, size_t i, size_t n, uint64_t sentinel)
+{
+    if (i >= n) return false;
+    const uint64_t k = key[i];
+    return k != sentinel && (i == 0 || (uint64_t)key[i - 1] != k);
+}
+
+template <class Key>
+__global__ void __launch_bounds__(kIndexBlock) k_head_count(const Key *key, size_t n, uint64_t sentinel, uint32_t *block_heads)
+{
+    __shared__ unsigned part[kIndexBlock / 64];
+    const size_t i = (size_t)blockIdx.x * kIndexBlock + threadIdx.x;
+    const unsigned long long m = __ballot(first_instance(key, i, n, sentinel));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned c = 0;
+        for (int w = 0; w < kIndexBlock / 64; ++w) c += part[w];
+        block_heads[blockIdx.x] = c;
+    }
+}
+
+template <class Key>
+__global__ void __launch_bounds__(kIndexBlock) k_index(const Key *key, const uint32_t *val,
+                        const uint32_t *block_base, size_t n, uint64_t sentinel, int per, int P, int G, int M,
                         int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys,
                         uint16_t *word_part, uint8_t *word_multi)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned part[kIndexBlock / 64];
+    const size_t i = (size_t)blockIdx.x * kIndexBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool first = first_instance(key, i, n, sentinel);
+    const unsigned long long fm = __ballot(first);
+    if (lane == 0) part[wave] = (unsigned)__popcll(fm);
+    __syncthreads();
     if (i >= n) return;
+    // first instances before this one: the blocks before, the waves before, the lanes before
+    uint32_t before = block_base[blockIdx.x] + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) before += part[w];
     const uint64_t k = key[i];
     const uint32_t inst = val[i];
     const uint32_t seg = inst / (uint32_t)per, q = inst % (uint32_t)per;
@@ -243,8 +267,7 @@ __global__ void k_index(const Key *key, const uint32_t *val,
         return;
     }
     if (i == n - 1) post_off[M] = (uint32_t)n;
-    const bool first = i == 0 || (uint64_t)key[i - 1] != k;   // HeadOf
-    const uint32_t kid = hscan[i] + (first ? 1u : 0u) - 1;
+    const uint32_t kid = before + (first ? 1u : 0u) - 1;
     kid_of_inst[slot] = (int32_t)kid;
     post[i] = seg;
     if (first) {
@@ -2273,12 +2296,12 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     const size_t n_inst = (size_t)n_seg * per;
     const uint64_t sentinel = 1ull << (2 * k);
     int rc;
-    // buffers: 0/1 keys, 2/3 vals, 4 (unused), 5 hscan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
+    // buffers: 0/1 keys, 2/3 vals, 4 (unused), 5 first instances per index block and their scan, 6 kid_of_inst, 7 post, 8 post_off, 9 ukeys,
     // 10 count+tied, 11 ignored, 12 coverage+stamp, 13 status/out, 14 cub temp, 16 the candidate-list loop's
     // PickState + per-word results (key, id, two partition bitmaps)
     if ((rc = ensure(0, n_inst * 8, err)) || (rc = ensure(1, n_inst * 8, err)) ||
         (rc = ensure(3, n_inst * 4, err)) ||
-        (rc = ensure(5, n_inst * 4, err)) ||
+        (rc = ensure(5, 2 * 4 * ((n_inst + kIndexBlock - 1) / kIndexBlock), err)) ||
         (rc = ensure(6, n_inst * 4, err)) || (rc = ensure(7, n_inst * 4, err)) ||
         (rc = ensure(8, (n_inst + 1) * 4, err)) || (rc = ensure(9, n_inst * 8, err)) ||
         (rc = ensure(10, n_inst * 8, err)) || (rc = ensure(11, ((size_t)n_seg + 7) & ~(size_t)3, err)) ||
@@ -2292,7 +2315,8 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     if ((rc = ensure(16, pick_bytes + res_bytes + multi_bytes + (size_t)kMaxMulti * 4, err))) return rc;
     uint64_t *key_a = (uint64_t *)buf_[0], *key_b = (uint64_t *)buf_[1];
     uint32_t *val_b = (uint32_t *)buf_[3];
-    uint32_t *hscan = (uint32_t *)buf_[5];
+    const size_t n_iblk = (n_inst + kIndexBlock - 1) / kIndexBlock;
+    uint32_t *block_heads = (uint32_t *)buf_[5], *block_base = block_heads + n_iblk;
     int32_t *kid_of_inst = (int32_t *)buf_[6];
     uint32_t *post = (uint32_t *)buf_[7], *post_off = (uint32_t *)buf_[8];
     uint64_t *ukeys = (uint64_t *)buf_[9];
@@ -2349,22 +2373,18 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         const bool nine = (key_bits + 8) / 9 < (key_bits + 7) / 8;
         KM_TRY(nine ? rocprim::radix_sort_pairs<Sort9>(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream)
                     : rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream));
-        const auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0u), HeadOf<Key>{kb, sentinel});
-        KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, heads, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
+        KM_TRY(rocprim::exclusive_scan(nullptr, tmp2, block_heads, block_base, 0u, n_iblk, rocprim::plus<uint32_t>(), stream));
         int rc2;
         if ((rc2 = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc2;
         KM_TRY(nine ? rocprim::radix_sort_pairs<Sort9>(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream)
                     : rocprim::radix_sort_pairs(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream));
-        const int g_inst = (int)((n_inst + 255) / 256);
-        KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, heads, hscan, 0u, n_inst, rocprim::plus<uint32_t>(), stream));
-        uint32_t last_head = 0, last_scan = 0;
-        Key last_keys[2] = {};   // the last instance's head flag, from the last two keys
-        const size_t n_last = n_inst >= 2 ? 2 : 1;
-        KM_TRY(hipMemcpyAsync(last_keys, kb + n_inst - n_last, sizeof(Key) * n_last, hipMemcpyDeviceToHost, stream));
-        KM_TRY(hipMemcpyAsync(&last_scan, hscan + n_inst - 1, 4, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(k_head_count<Key>, dim3((unsigned)n_iblk), dim3(kIndexBlock), 0, stream, kb, n_inst, sentinel, block_heads);
+        KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, block_heads, block_base, 0u, n_iblk, rocprim::plus<uint32_t>(), stream));
+        uint32_t last_heads = 0, last_base = 0;   // the number of words: the last block's base + its own first instances
+        KM_TRY(hipMemcpyAsync(&last_heads, block_heads + n_iblk - 1, 4, hipMemcpyDeviceToHost, stream));
+        KM_TRY(hipMemcpyAsync(&last_base, block_base + n_iblk - 1, 4, hipMemcpyDeviceToHost, stream));
         KM_TRY(hipStreamSynchronize(stream));
-        last_head = ((uint64_t)last_keys[n_last - 1] != sentinel && (n_last == 1 || last_keys[0] != last_keys[1])) ? 1u : 0u;
-        M = (int)(last_head + last_scan);
+        M = (int)(last_heads + last_base);
         if (M == 0) return MSSPE_OK;
         // number of valid instances = first sentinel position: post_off[M]
         const size_t wp_bytes = ((size_t)M * 3 + 15) & ~(size_t)15, lp_bytes = (4 * (size_t)P + 15) & ~(size_t)15;
@@ -2392,7 +2412,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
             fj.count = nj;
             hipLaunchKernelGGL(k_fill_jobs, dim3(512), dim3(256), 0, stream, fj);
         }
-        hipLaunchKernelGGL(k_index<Key>, dim3(g_inst), dim3(256), 0, stream, kb, val_b, hscan, n_inst,
+        hipLaunchKernelGGL(k_index<Key>, dim3((unsigned)n_iblk), dim3(kIndexBlock), 0, stream, kb, val_b, block_base, n_inst,
                            sentinel, per, (int)P, n_seq, M, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
         return MSSPE_OK;
     };
