@@ -608,10 +608,20 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     // list_cap_log2 below 29, or lists shrunk because the card is short of memory): even a launch that handed
     // every pair on cannot overrun its list.
     const long chunk_pairs = std::min(kChunkPairs, kListCap);
-    long rows_per_chunk = chunk_pairs / ncols;
-    // whole row groups of the first-stage kernels (12 or 8 waves per block): no idle waves in the
-    // last tile row of a launch
-    if (rows_per_chunk > 24) rows_per_chunk -= rows_per_chunk % 24;
+    // The block's rows are split evenly over as few launches as the limit allows (a 65,536-row block: nine launches of
+    // about 7,296 rows rather than eight of 8,184 and one of 64; the 8,192 rows a rank of eight owns: one launch, not
+    // 8,184 + 8), in whole row groups of the first-stage kernels (12 or 8 waves per block: no idle waves in the last
+    // tile row of a launch that is not the block's last).
+    const long max_rows = std::max(1L, chunk_pairs / ncols), n_rows_all = (long)row1 - row0;
+    long rows_per_chunk = max_rows;
+    if (n_rows_all > max_rows) {
+        const long cap_rows = max_rows > 24 ? max_rows - max_rows % 24 : max_rows;   // the largest whole-group launch
+        const long n_launch = (n_rows_all + cap_rows - 1) / cap_rows;
+        rows_per_chunk = (n_rows_all + n_launch - 1) / n_launch;
+        if (rows_per_chunk > 24) rows_per_chunk = std::min(cap_rows, (rows_per_chunk + 23) / 24 * 24);
+    } else if (n_rows_all > 0) {
+        rows_per_chunk = n_rows_all;
+    }
     if (rows_per_chunk < 1) rows_per_chunk = 1;
     if (!fast) {
         // generic kernel over the whole block, a band of rows per launch (matrix mode derives
