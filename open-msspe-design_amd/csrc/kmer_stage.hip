@@ -214,68 +214,115 @@ __global__ void __launch_bounds__(256) k_extract(const uint64_t *packed, size_t 
 // instances are counted per block of 256 keys (k_head_count), a small scan turns the 176 k counts into the blocks'
 // bases, and k_index finishes the numbering inside its block with ballots.  (A scan over the 45 M flags, and the
 // flags themselves, cost 0.37 ms more; reading them through a transform iterator 0.25.)
-constexpr int kIndexBlock = 256;
+constexpr int kIndexBlock = 256;   // keys per index block: one WAVE's, four consecutive keys per lane (16- / 32-byte loads)
 
-template <class Key>
-__device__ __forceinline__ bool first_instance(const Key *key, size_t i, size_t n, uint64_t sentinel)
+// The four keys (and, for k_index, instance numbers) of lane `lane` of index block `blk`, and the element before them.
+template <class T>
+__device__ __forceinline__ void load4(const T *p, size_t i0, size_t n, T (&v)[4], T &before)
 {
-    if (i >= n) return false;
-    const uint64_t k = key[i];
-    return k != sentinel && (i == 0 || (uint64_t)key[i - 1] != k);
-}
-
-template <class Key>
-__global__ void __launch_bounds__(kIndexBlock) k_head_count(const Key *key, size_t n, uint64_t sentinel, uint32_t *block_heads)
-{
-    __shared__ unsigned part[kIndexBlock / 64];
-    const size_t i = (size_t)blockIdx.x * kIndexBlock + threadIdx.x;
-    const unsigned long long m = __ballot(first_instance(key, i, n, sentinel));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (unsigned)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned c = 0;
-        for (int w = 0; w < kIndexBlock / 64; ++w) c += part[w];
-        block_heads[blockIdx.x] = c;
+    if (i0 + 4 <= n) {
+        if constexpr (sizeof(T) == 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(p + i0);
+            v[0] = (T)q.x, v[1] = (T)q.y, v[2] = (T)q.z, v[3] = (T)q.w;
+        } else {
+            const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(p + i0), q1 = *reinterpret_cast<const ulonglong2 *>(p + i0 + 2);
+            v[0] = (T)q0.x, v[1] = (T)q0.y, v[2] = (T)q1.x, v[3] = (T)q1.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = i0 + j < n ? p[i0 + j] : (T)0;
     }
+    before = i0 > 0 && i0 <= n ? p[i0 - 1] : (T)0;
+}
+
+// bit j: element j of the lane's four is the first instance of its word
+template <class Key>
+__device__ __forceinline__ unsigned first_instances4(const Key (&k)[4], Key before, size_t i0, size_t n, uint64_t sentinel)
+{
+    unsigned f = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t prev = j ? (uint64_t)k[j - 1] : (uint64_t)before;
+        const bool first = i0 + j < n && (uint64_t)k[j] != sentinel && (i0 + j == 0 || prev != (uint64_t)k[j]);
+        f |= first ? 1u << j : 0u;
+    }
+    return f;
 }
 
 template <class Key>
-__global__ void __launch_bounds__(kIndexBlock) k_index(const Key *key, const uint32_t *val,
-                        const uint32_t *block_base, size_t n, uint64_t sentinel, int per, int P, int G, int M,
+__global__ void __launch_bounds__(256) k_head_count(const Key *key, size_t n, uint64_t sentinel, uint32_t *block_heads, size_t n_iblk)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+    if (blk >= n_iblk) return;
+    const size_t i0 = blk * kIndexBlock + 4 * (size_t)lane;
+    Key k[4], before;
+    load4(key, i0, n, k, before);
+    const unsigned f = first_instances4(k, before, i0, n, sentinel);
+    unsigned c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (unsigned)__popcll(__ballot((f >> j) & 1u));
+    if (lane == 0) block_heads[blk] = c;
+}
+
+template <class Key>
+__global__ void __launch_bounds__(256) k_index(const Key *key, const uint32_t *val,
+                        const uint32_t *block_base, size_t n, size_t n_iblk, uint64_t sentinel, int per, int P, int G, int M,
                         int32_t *kid_of_inst, uint32_t *post, uint32_t *post_off, uint64_t *ukeys,
                         uint16_t *word_part, uint8_t *word_multi)
 {
-    __shared__ unsigned part[kIndexBlock / 64];
-    const size_t i = (size_t)blockIdx.x * kIndexBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool first = first_instance(key, i, n, sentinel);
-    const unsigned long long fm = __ballot(first);
-    if (lane == 0) part[wave] = (unsigned)__popcll(fm);
-    __syncthreads();
-    if (i >= n) return;
-    // first instances before this one: the blocks before, the waves before, the lanes before
-    uint32_t before = block_base[blockIdx.x] + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) before += part[w];
-    const uint64_t k = key[i];
-    const uint32_t inst = val[i];
-    const uint32_t seg = inst / (uint32_t)per, q = inst % (uint32_t)per;
-    const size_t slot = ((size_t)(seg % (uint32_t)P) * per + q) * (uint32_t)G + seg / (uint32_t)P;   // inst_slot of its row
-    // post_off[M] = number of non-sentinel instances (sentinels sort last)
-    if (k == sentinel) {
-        kid_of_inst[slot] = -1;
-        if (i == 0 || (uint64_t)key[i - 1] != sentinel) post_off[M] = (uint32_t)i;
-        return;
+    const int lane = threadIdx.x & 63;
+    const size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+    if (blk >= n_iblk) return;
+    const size_t i0 = blk * kIndexBlock + 4 * (size_t)lane;
+    Key k[4], kbefore;
+    uint32_t inst[4], ibefore;
+    load4(key, i0, n, k, kbefore);
+    load4(val, i0, n, inst, ibefore);
+    const unsigned f = first_instances4(k, kbefore, i0, n, sentinel);
+    // first instances before this lane's elements: the blocks before, the lanes before
+    uint32_t before = block_base[blk];
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) before += (uint32_t)__popcll(__ballot((f >> j) & 1u) & below);
+    uint32_t segs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t i = i0 + j;
+        const uint32_t seg = inst[j] / (uint32_t)per, q = inst[j] % (uint32_t)per;
+        segs[j] = seg;
+        if (i >= n) continue;
+        const size_t slot = ((size_t)(seg % (uint32_t)P) * per + q) * (uint32_t)G + seg / (uint32_t)P;   // inst_slot of its row
+        const uint64_t kk = (uint64_t)k[j];
+        const uint64_t kprev = j ? (uint64_t)k[j - 1] : (uint64_t)kbefore;
+        // post_off[M] = number of non-sentinel instances (sentinels sort last)
+        if (kk == sentinel) {
+            kid_of_inst[slot] = -1;
+            if (i == 0 || kprev != sentinel) post_off[M] = (uint32_t)i;
+            continue;
+        }
+        if (i == n - 1) post_off[M] = (uint32_t)n;
+        const bool first = (f >> j) & 1u;
+        before += first ? 1u : 0u;      // (now: first instances up to and including this element)
+        const uint32_t kid = before - 1;
+        kid_of_inst[slot] = (int32_t)kid;
+        if (first) {
+            post_off[kid] = (uint32_t)i;
+            ukeys[kid] = kk;
+            word_part[kid] = (uint16_t)(seg % (uint32_t)P);   // the partition of the word's first posting ...
+        } else {
+            const uint32_t iprev = j ? inst[j - 1] : ibefore;
+            if ((iprev / (uint32_t)per) % (uint32_t)P != seg % (uint32_t)P)
+                word_multi[kid] = 1;   // ... and whether any two neighbouring postings differ in theirs (cleared by the host)
+        }
     }
-    if (i == n - 1) post_off[M] = (uint32_t)n;
-    const uint32_t kid = before + (first ? 1u : 0u) - 1;
-    kid_of_inst[slot] = (int32_t)kid;
-    post[i] = seg;
-    if (first) {
-        post_off[kid] = (uint32_t)i;
-        ukeys[kid] = k;
-        word_part[kid] = (uint16_t)(seg % (uint32_t)P);   // the partition of the word's first posting ...
-    } else if ((val[i - 1] / (uint32_t)per) % (uint32_t)P != seg % (uint32_t)P) {
-        word_multi[kid] = 1;   // ... and whether any two neighbouring postings differ in theirs (cleared by the host)
+    // post[i] = the instance's segment (read up to post_off[M] only: the sentinel run's entries are never looked at)
+    if (i0 + 4 <= n) {
+        *reinterpret_cast<uint4 *>(post + i0) = make_uint4(segs[0], segs[1], segs[2], segs[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) post[i0 + j] = segs[j];
     }
 }
 
@@ -2378,7 +2425,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         if ((rc2 = ensure(14, std::max(tmp_bytes, tmp2), err))) return rc2;
         KM_TRY(nine ? rocprim::radix_sort_pairs<Sort9>(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream)
                     : rocprim::radix_sort_pairs(buf_[14], tmp_bytes, ka, kb, val_a, val_b, n_inst, 0u, key_bits, stream));
-        hipLaunchKernelGGL(k_head_count<Key>, dim3((unsigned)n_iblk), dim3(kIndexBlock), 0, stream, kb, n_inst, sentinel, block_heads);
+        hipLaunchKernelGGL(k_head_count<Key>, dim3((unsigned)((n_iblk + 3) / 4)), dim3(256), 0, stream, kb, n_inst, sentinel, block_heads, n_iblk);
         KM_TRY(rocprim::exclusive_scan(buf_[14], tmp2, block_heads, block_base, 0u, n_iblk, rocprim::plus<uint32_t>(), stream));
         uint32_t last_heads = 0, last_base = 0;   // the number of words: the last block's base + its own first instances
         KM_TRY(hipMemcpyAsync(&last_heads, block_heads + n_iblk - 1, 4, hipMemcpyDeviceToHost, stream));
@@ -2412,7 +2459,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
             fj.count = nj;
             hipLaunchKernelGGL(k_fill_jobs, dim3(512), dim3(256), 0, stream, fj);
         }
-        hipLaunchKernelGGL(k_index<Key>, dim3((unsigned)n_iblk), dim3(kIndexBlock), 0, stream, kb, val_b, block_base, n_inst,
+        hipLaunchKernelGGL(k_index<Key>, dim3((unsigned)((n_iblk + 3) / 4)), dim3(256), 0, stream, kb, val_b, block_base, n_inst, n_iblk,
                            sentinel, per, (int)P, n_seq, M, kid_of_inst, post, post_off, ukeys, word_part, word_multi);
         return MSSPE_OK;
     };
