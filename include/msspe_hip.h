@@ -329,6 +329,13 @@ void msspe_group_destroy(msspe_group *g);
 const char *msspe_group_last_error(const msspe_group *g);
 int msspe_group_size(const msspe_group *g);
 const char *msspe_group_transport(const msspe_group *g);          /* "single" | "rccl" | "device-copy" */
+/* "" unless transport "auto" wanted RCCL and runs the copies instead: then why (librccl.so not loadable,
+ * ncclCommInitAll's error, or the failure of the first grouped collective, which msspe_group_create runs with a
+ * known answer before any screen depends on the fabric) */
+const char *msspe_group_transport_reason(const msspe_group *g);
+/* Host only, no device: 1 if RCCL (library: NULL = the names msspe_group_create tries) can be loaded with every
+ * collective entry point the group uses, else 0 and the reason in why[0 .. why_capacity) */
+int msspe_group_rccl_available(const char *library, char *why, int why_capacity);
 msspe_ctx *msspe_group_member(msspe_group *g, int member);        /* owned by the group */
 int msspe_group_set_option(msspe_group *g, const char *key, const char *value);   /* msspe_set_option on every member */
 /* pool rows member `member` of a group of n_members screens in a pool of n (ascending).  Host only, no device.

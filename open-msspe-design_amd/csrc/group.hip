@@ -50,14 +50,24 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    bool load(std::string &err)
+    // `only`: try this library name alone (msspe_group_rccl_available's argument); else the usual names
+    bool load(std::string &err, const char *only = nullptr)
     {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        std::string why;
+        auto attempt = [&](const char *name) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
+            if (!lib) {
+                const char *e = dlerror();   // one call: dlerror() clears the message it returns
+                why = e ? e : "?";
+            }
+            return lib != nullptr;
+        };
+        if (only) attempt(only);
+        else
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if (attempt(name)) break;
         if (!lib) {
-            err = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "?");
+            err = std::string(only ? only : "librccl.so") + " not loadable: " + why;
             return false;
         }
         auto sym = [&](const char *n) { return dlsym(lib, n); };
@@ -109,7 +119,10 @@ struct Member {
     uint32_t *block_counts = nullptr;   // counts as the context writes them (indexed by P' row)
     uint32_t *counts = nullptr;         // counts by pool index (what is all-reduced)
     uint32_t *scratch = nullptr;        // copy transport: another member's counts
-    size_t shard_cap = 0, pool_cap = 0, rows_cap = 0, counts_cap = 0, block_cap = 0, scratch_cap = 0;
+    msspe_edge_dev *edges = nullptr;    // edge records of the member's rows, kept across calls
+    uint64_t *edge_count = nullptr;
+    size_t shard_cap = 0, pool_cap = 0, rows_cap = 0, counts_cap = 0, block_cap = 0, scratch_cap = 0, edges_cap = 0,
+           edge_count_cap = 0;
     std::vector<uint32_t> h_rows;
     int rc = 0;
     std::string err;
@@ -120,6 +133,7 @@ struct Member {
 struct msspe_group {
     std::vector<Member> mem;
     std::string transport = "single";   // "single" | "rccl" | "device-copy"
+    std::string transport_reason;       // why the copies run where RCCL was wanted ("" otherwise)
     Rccl rccl;
     std::vector<void *> comms;
     std::string err;
@@ -221,7 +235,7 @@ int all_gather_u64(msspe_group *g, size_t count)
 int all_reduce_sum_u32(msspe_group *g, size_t count)
 {
     const size_t N = g->mem.size();
-    if (N == 1) return MSSPE_OK;
+    if (N == 1 && g->transport != "rccl") return MSSPE_OK;   // (one RCCL rank still goes through RCCL: the tests' rehearsal)
     if (g->transport == "rccl") {
         int rc = g->rccl.GroupStart();
         for (size_t m = 0; m < N && rc == 0; ++m)
@@ -294,6 +308,43 @@ int assemble_pool(msspe_group *g, const char *pool_ascii, int n, int k, size_t *
     });
 }
 
+// The first collective of a group, with a known answer (msspe_group_create): false + `why` when RCCL's grouped
+// all-reduce fails or returns anything but the sum, so that "auto" can fall back to the copies before a screen runs.
+bool rccl_self_test(msspe_group *g, std::string &why)
+{
+    const size_t N = g->mem.size();
+    std::vector<uint32_t> got(N, 0);
+    for (size_t m = 0; m < N; ++m) {
+        Member &mb = g->mem[m];
+        const uint32_t v = 1u + (uint32_t)m;
+        if (hipSetDevice(mb.device) != hipSuccess || grow(mb.counts, mb.counts_cap, 64) != hipSuccess ||
+            hipMemcpyAsync(mb.counts, &v, sizeof v, hipMemcpyHostToDevice, mb.stream) != hipSuccess ||
+            hipStreamSynchronize(mb.stream) != hipSuccess) {
+            why = "RCCL self-test: device buffer on member " + std::to_string(m);
+            return false;
+        }
+    }
+    if (all_reduce_sum_u32(g, 1) != MSSPE_OK) {
+        why = "RCCL self-test: " + g->err;
+        return false;
+    }
+    for (size_t m = 0; m < N; ++m) {
+        Member &mb = g->mem[m];
+        if (hipSetDevice(mb.device) != hipSuccess || hipStreamSynchronize(mb.stream) != hipSuccess ||
+            hipMemcpy(&got[m], mb.counts, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            why = std::string("RCCL self-test: the all-reduce did not complete on member ") + std::to_string(m) + ": " +
+                  hipGetErrorString(hipGetLastError());
+            return false;
+        }
+        if (got[m] != (uint32_t)(N * (N + 1) / 2)) {
+            why = "RCCL self-test: all-reduce returned " + std::to_string(got[m]) + " on member " + std::to_string(m) +
+                  ", expected " + std::to_string(N * (N + 1) / 2);
+            return false;
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -336,9 +387,23 @@ int msspe_group_create(const int *devices, int n_devices, const char *params_pat
                 g->comms.clear();
             }
         }
+        // a first grouped collective with a known answer, before any screen depends on the fabric: every member
+        // contributes 1 + its index, every member must read N (N + 1) / 2 back
+        if (ok) {
+            g->transport = "rccl";
+            ok = rccl_self_test(g, why);
+            if (!ok) {
+                for (void *c : g->comms)
+                    if (c) (void)g->rccl.CommDestroy(c);
+                g->comms.clear();
+            }
+        }
         if (ok) g->transport = "rccl";
         else if (want == "rccl") return gfail(g, MSSPE_ERR_DEVICE, why);
-        else g->transport = "device-copy";   // auto: the copies work between any two devices of a node
+        else {
+            g->transport = "device-copy";   // auto: the copies work between any two devices of a node
+            g->transport_reason = why;
+        }
     } else {
         g->transport = n_devices > 1 ? "device-copy" : "single";
     }
@@ -370,7 +435,8 @@ void msspe_group_destroy(msspe_group *g)
         if (c && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(c);
     for (auto &m : g->mem) {
         (void)hipSetDevice(m.device);
-        for (void *p : {(void *)m.shard, (void *)m.pool, (void *)m.rows, (void *)m.block_counts, (void *)m.counts, (void *)m.scratch})
+        for (void *p : {(void *)m.shard, (void *)m.pool, (void *)m.rows, (void *)m.block_counts, (void *)m.counts, (void *)m.scratch,
+                        (void *)m.edges, (void *)m.edge_count})
             if (p) (void)hipFree(p);
         if (m.ctx) msspe_destroy(m.ctx);
     }
@@ -381,6 +447,19 @@ void msspe_group_destroy(msspe_group *g)
 const char *msspe_group_last_error(const msspe_group *g) { return g ? g->err.c_str() : "null group"; }
 int msspe_group_size(const msspe_group *g) { return g ? (int)g->mem.size() : 0; }
 const char *msspe_group_transport(const msspe_group *g) { return g ? g->transport.c_str() : ""; }
+const char *msspe_group_transport_reason(const msspe_group *g) { return g ? g->transport_reason.c_str() : ""; }
+
+int msspe_group_rccl_available(const char *library, char *why, int why_capacity)
+{
+    Rccl r;
+    std::string err;
+    const bool ok = r.load(err, library && *library ? library : nullptr);
+    if (why && why_capacity > 0) {
+        std::strncpy(why, ok ? "" : err.c_str(), (size_t)why_capacity - 1);
+        why[why_capacity - 1] = 0;
+    }
+    return ok ? 1 : 0;   // (a library that loaded stays mapped, as in msspe_group_create)
+}
 msspe_ctx *msspe_group_member(msspe_group *g, int member)
 {
     return g && member >= 0 && member < (int)g->mem.size() ? g->mem[(size_t)member].ctx : nullptr;
@@ -484,28 +563,25 @@ int msspe_cross_dimer_edges_group(msspe_group *g, const char *pool_ascii, int n,
     rc = on_every_member(g, [&](int mi) {
         Member &m = g->mem[(size_t)mi];
         const int mr = (int)m.h_rows.size();
-        if (!mr) return;
-        msspe_edge_dev *d_edges = nullptr;
-        uint64_t *d_count = nullptr;
-        auto done = [&]() {
-            if (d_edges) (void)hipFree(d_edges);
-            if (d_count) (void)hipFree(d_count);
-        };
-        M_HIP(m, hipMalloc((void **)&d_count, sizeof(uint64_t)));
-        if (capacity) {
-            const hipError_t e = hipMalloc((void **)&d_edges, sizeof(msspe_edge_dev) * (size_t)capacity);
-            if (e != hipSuccess) {
-                done();
-                M_HIP(m, e);
-            }
+        if (!mr) {
+            // nothing to screen, but this member's stream still carries the all-gather's copies out of the other
+            // members' shards: they must be done before the next call overwrites those shards
+            M_HIP(m, hipStreamSynchronize(m.stream));
+            return;
         }
+        // the member's edge records stay allocated across calls (grown on demand): a member may hold up to
+        // `capacity` edges -- which rows conflict is not known beforehand -- but on its own device
+        M_HIP(m, grow(m.edge_count, m.edge_count_cap, 1));
+        if (capacity) M_HIP(m, grow(m.edges, m.edges_cap, (size_t)capacity));
+        msspe_edge_dev *d_edges = capacity ? m.edges : nullptr;
+        uint64_t *d_count = m.edge_count;
         int prc = msspe_cross_dimer_edges_dev(m.ctx, m.pool, (int)(n_base + (size_t)mr), k, chem, dg_threshold, (int)n_base,
                                               (int)n_base + mr, 0, n, nullptr, d_edges, capacity, d_count);
         if (!prc) prc = msspe_synchronize(m.ctx);
         if (prc) {
             m.rc = prc;
             m.err = msspe_last_error(m.ctx);
-            done();
+            (void)hipStreamSynchronize(m.stream);
             return;
         }
         uint64_t c = 0;
@@ -519,7 +595,6 @@ int msspe_cross_dimer_edges_group(msspe_group *g, const char *pool_ascii, int n,
             if (e == hipSuccess) e = hipMemcpy(got[(size_t)mi].data(), d_edges, sizeof(msspe_edge_dev) * have, hipMemcpyDeviceToHost);
         }
         counts[(size_t)mi] = c;
-        done();
         M_HIP(m, e);
     });
     if (rc) return rc;

@@ -2569,8 +2569,12 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     Status *h_pin = (Status *)pinned_;
     Status h = h0;
     int wide_left = 0;   // five-launch batches still to run after a candidate list came out too long
+    bool out_of_batches = false;
     for (int batch = 0; !h.stop; ++batch) {
-        if (narrow_ok ? batch >= 2 * h0.max_iter + 4 : batch * kBatch >= h0.max_iter + 1) break;
+        if (narrow_ok ? batch >= 2 * h0.max_iter + 4 : batch * kBatch >= h0.max_iter + 1) {
+            out_of_batches = true;
+            break;
+        }
         const int which = narrow_ok && wide_left == 0 ? 1 : 0;
         if (wide_left) --wide_left;
         if (which && h.need_rebuild == 1) enqueue_rebuild(stream);
@@ -2598,6 +2602,12 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
         KM_TRY(hipStreamSynchronize(stream));
         h = *h_pin;
         if (which && h.too_many) wide_left = 4;
+    }
+    if (out_of_batches && !h.stop) {
+        // every batch selects a winner or stops the loop; a loop that used up its bound without the device's stop
+        // flag would return a truncated list as if it were whole
+        err = "stage A: the greedy loop did not finish within its batch bound (" + std::to_string(h.n_win) + " winners so far)";
+        return MSSPE_ERR_DEVICE;
     }
     const int n_win = h.n_win;
     loop_stats_[0] = h.it_fast;

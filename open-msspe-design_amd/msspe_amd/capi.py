@@ -25,7 +25,7 @@ EXPORTS = [
     "msspe_segment_coverage_packed_dev",
     "msspe_round_fixed_f32", "msspe_g_cut",
     "msspe_group_create", "msspe_group_destroy", "msspe_group_last_error", "msspe_group_size",
-    "msspe_group_transport", "msspe_group_member", "msspe_group_set_option", "msspe_group_rows",
+    "msspe_group_transport", "msspe_group_transport_reason", "msspe_group_rccl_available", "msspe_group_member", "msspe_group_set_option", "msspe_group_rows",
     "msspe_cross_dimer_group", "msspe_cross_dimer_edges_group", "msspe_oligo_stats_group",
 ]
 
@@ -105,6 +105,9 @@ def load_library() -> C.CDLL:
     L.msspe_group_size.argtypes = [vp]
     L.msspe_group_transport.argtypes = [vp]
     L.msspe_group_transport.restype = C.c_char_p
+    L.msspe_group_transport_reason.argtypes = [vp]
+    L.msspe_group_transport_reason.restype = C.c_char_p
+    L.msspe_group_rccl_available.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     L.msspe_group_member.argtypes = [vp, C.c_int]
     L.msspe_group_member.restype = vp
     L.msspe_group_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
@@ -439,6 +442,13 @@ def group_rows(n: int, n_members: int, member: int) -> np.ndarray:
     return rows[:cnt.value]
 
 
+def rccl_available(library: str | None = None) -> tuple[bool, str]:
+    """(loadable with every entry point the group uses, reason if not) -- msspe_group_rccl_available; host only."""
+    why = C.create_string_buffer(512)
+    ok = load_library().msspe_group_rccl_available(library.encode() if library else None, why, 512)
+    return bool(ok), why.value.decode()
+
+
 class Group:
     """Several devices of one node in one process (include/msspe_hip.h msspe_group_*): one context per listed
     device; a device listed more than once = members sharing a card (the rehearsal mode, transport device-copy)."""
@@ -478,6 +488,11 @@ class Group:
     @property
     def transport(self) -> str:
         return self.L.msspe_group_transport(self.ptr).decode()
+
+    @property
+    def transport_reason(self) -> str:
+        """Why the copies run where transport "auto" wanted RCCL ("" otherwise)."""
+        return self.L.msspe_group_transport_reason(self.ptr).decode()
 
     def set_option(self, key: str, value) -> None:
         self._check(self.L.msspe_group_set_option(self.ptr, key.encode(), str(value).encode()))

@@ -86,15 +86,18 @@ def run(fasta: str, *, kmer_size=13, window_size=500, overlap_size=250, search_w
         max_iterations=1000, max_mismatch_segments=None, keep_all=False, check_cross_dimers=True,
         check_self_dimers=True, check_hairpin=True, tm_stddev=2.0, disable_tm_stddev=False,
         disable_min_max_tm=False, min_tm=30.0, max_tm=60.0, max_any=47.0, max_end=47.0, max_hairpin=24.0,
-        mv=50.0, dv=3.0, dntp=0.0, dna=250.0, temp=25.0, dg=-9000.0, sample_stddev=True):
+        mv=50.0, dv=3.0, dntp=0.0, dna=250.0, temp=25.0, dg=-9000.0, sample_stddev=True, candidates=None):
+    """candidates: optional {direction: [(word, frequency), ...]} already produced by Segments.candidates with
+    the same options (tools/make_config2_fixture.py runs stage A once and keeps the lists)."""
     recs = to_records(fasta)
     tables = o.Tables()
     mm = max_mismatch_segments if max_mismatch_segments is not None else min(10, max(1, -(-len(recs) // 50)))
-    segs = o.Segments([s for _, s in recs], window_size, overlap_size, search_windows_size, kmer_size)
+    segs = None if candidates is not None else \
+        o.Segments([s for _, s in recs], window_size, overlap_size, search_windows_size, kmer_size)
     f32 = np.float32
     result = {}
     for d in (0, 1):
-        cand = segs.candidates(d, max_iterations, mm)
+        cand = candidates[d] if candidates is not None else segs.candidates(d, max_iterations, mm)
         words = [w for w, _ in cand]
         stats = []
         if words:

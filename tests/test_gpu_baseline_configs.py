@@ -4,9 +4,12 @@ configs[0]  10 pre-aligned ~29.9 kb genomes, --kmer-size 13 --check-hairpin true
             run against the restated pipeline.
 configs[1]  1,000 synthetic aligned 30 kb genomes, Tm + hairpin + self-dimer filters: the whole CLI run
             against the oracle-based restatement of main.rs (CSV + coverage report byte for byte).
-configs[2]  10,000 x 30 kb: stage A's first winners re-counted on the CPU, independently of the oracle's
-            restatement (which needs minutes at this size): each winner's frequency is the number of live
-            segments holding it AND the maximum over all k-mers of the live segments (main.rs:285-329).
+configs[2]  10,000 x 30 kb: both directions' WHOLE winner sequences (611 / 614 winners with their frequencies) equal
+            the oracle's, which ran at full size in the build container (tools/make_config2_fixture.py ->
+            tests/golden/config2_10k.json), through the candidate-list loop and the all-words loop; the whole CLI
+            run on the 300 MB FASTA reproduces the fixture's CSV hash and coverage report (main.rs:331-406, :596-861);
+            and the first winners are re-counted on the CPU independently of the oracle: each winner's frequency is
+            the number of live segments holding it AND the maximum over all k-mers of the live segments (main.rs:285-329).
 configs[3]  the 1,048,576-candidate pool: a slice of the row block rank 3 of 8 owns and the pool's last rows, against
             all 2^20 columns (row x column products beyond 2^32, column indices up to 2^20 - 1): counts are the
             popcounts of the bitmap rows and sampled rows equal the oracle's decisions (delta_g.rs:61-81).
@@ -167,9 +170,70 @@ def _head_window_keys(genomes: np.ndarray, seg=500, stride=250, win=50, k=13):
     return keys, parts
 
 
-def test_config2_10000_genomes_stage_a_winners_are_maximal_and_counted_right(m):
+@pytest.fixture(scope="module")
+def config2(m, golden_dir):
+    import json
+    fx = json.loads((golden_dir / "config2_10k.json").read_text())
+    return fx, m.synth.aligned_genomes(fx["rows"], fx["length"])
+
+
+def test_config2_10000_genomes_both_directions_equal_the_full_size_oracle_fixture(m, config2):
+    """msspe_kmer_candidates_packed_dev at BASELINE configs[2]'s size, winner for winner against the oracle's lists
+    (both loop drivers), and the multi-winner loop used every kind of selection on the way."""
+    fx, genomes = config2
+    o = fx["options"]
+    opt = m.KmerOpt(o["segment"], o["stride"], o["window"], o["k"], o["max_iterations"], o["max_mismatch_segments"])
+    eng = m.Engine(0)
+    kinds = set()
+    try:
+        d_rows = eng.put_rows_packed(genomes)
+        for direction in (0, 1):
+            want = [(w, f) for w, f in fx["winners"][str(direction)]]
+            for cand in (1, 0):
+                eng.set_option("stage_a_candidates", cand)
+                try:
+                    words, freqs = eng.kmer_candidates_packed(d_rows, genomes.shape[0], genomes.shape[1], opt, direction)
+                finally:
+                    eng.set_option("stage_a_candidates", 1)
+                got = list(zip(words, freqs.tolist()))
+                first = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))
+                assert got == want, (direction, cand, len(got), len(want), first, got[first:first + 2], want[first:first + 2])
+                if cand:
+                    tr = eng.kmer_trace()
+                    assert len(tr) == len(want)
+                    kinds |= set(tr[:, 1].tolist())
+        eng.device_free(d_rows)
+    finally:
+        eng.close()
+    # 1 a partition's leader, 2 a several-partition word, 3 one whose key was re-computed (include/msspe_hip.h)
+    assert {1, 2, 3} <= kinds, kinds
+
+
+def test_config2_10000_genomes_cli_reproduces_the_fixture_csv_and_report(m, config2, tmp_path):
+    import hashlib
+    fx, genomes = config2
+    fa, csv = tmp_path / "in.fa", tmp_path / "out.csv"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(genomes):
+            f.write(b">genome%d\n" % i)
+            f.write(r.tobytes())
+            f.write(b"\n")
+    rc, report = _run_cli(m, ["od-msspe-hip", "-i", str(fa), "-o", str(csv), "--do-align", "false", "--check-hairpin", "true",
+                              "--check-self-dimers", "true"])
+    assert rc == 0, report
+    text = csv.read_text()
+    got = {"F": [], "R": []}
+    for line in text.splitlines()[1:]:
+        f = line.split(",")
+        got[f[0]].append(f[2])
+    assert got == fx["primers_kept"]
+    assert hashlib.sha256(text.encode()).hexdigest() == fx["csv_sha256"]
+    assert report == fx["report"]
+
+
+def test_config2_10000_genomes_stage_a_winners_are_maximal_and_counted_right(m, config2):
     n_rows, length, k, check = 10000, 30000, 13, 24
-    genomes = m.synth.aligned_genomes(n_rows, length)
+    genomes = config2[1]
     eng = m.Engine(0)
     try:
         words, freqs = eng.kmer_candidates(genomes, m.KmerOpt(500, 250, 50, k, 1000, 10), 0)

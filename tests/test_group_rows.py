@@ -38,3 +38,18 @@ def test_bad_arguments_are_refused(m):
         m.group_rows(10, 2, 2)
     with pytest.raises(m.MsspeError):
         m.group_rows(-1, 2, 0)
+
+
+def test_rccl_probe_reports_a_library_that_cannot_be_loaded(m):
+    """group.hip's loader with the library name forced to a file that does not exist: a reason, no crash (the message
+    used to be built from a second dlerror() call, which returns NULL) -- the branch transport "auto" takes when a
+    multi-GPU node has no RCCL."""
+    from msspe_amd.capi import rccl_available
+    ok, why = rccl_available("/nonexistent/librccl-not-here.so.1")
+    assert not ok
+    assert "librccl-not-here" in why and "not loadable" in why
+    ok2, why2 = rccl_available("/nonexistent/librccl-not-here.so.1")      # and again: dlerror state does not linger
+    assert (ok2, why2) == (ok, why)
+    # an existing library without the collective entry points is refused with its own reason
+    ok3, why3 = rccl_available("libm.so.6")
+    assert not ok3 and "entry point" in why3

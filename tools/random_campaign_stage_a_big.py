@@ -4,7 +4,14 @@ regime the fast path is made for -- hundreds to thousands of near-identical rows
 that stress it: duplicated column blocks (words with many postings in SEVERAL partitions), clades (several
 ancestors), gaps and N runs.  The candidate-list loop against the all-words loop (one winner per iteration: round 1's
 loop, itself checked against the oracle by the other campaign), both directions, whole winner sequences with their
-frequencies; the oracle too where the case is small.  usage: random_campaign_stage_a_big.py [seed] [cases]"""
+frequencies; AND against the oracle: through the committed hashes of the oracle's winner sequences where
+tests/golden/stage_a_big_campaign.json holds the case (the fixed-seed cases the suite runs), else by running the oracle
+beside the GPU where the case is affordable (rows x L <= 12,000,000).
+usage: random_campaign_stage_a_big.py [seed] [cases] [only]                 (GPU)
+       random_campaign_stage_a_big.py --oracle-hashes seed cases [seed cases ...]   (build container, no GPU: writes
+                                                                                    the hashes of every case)"""
+import hashlib
+import json
 import sys
 from pathlib import Path
 
@@ -12,16 +19,18 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "open-msspe-design_amd"))
 sys.path.insert(0, str(ROOT / "oracle"))
 import numpy as np
-import msspe_amd as m
 import pyoracle as o
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
-cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-only = int(sys.argv[3]) if len(sys.argv) > 3 else -1    # evaluate this case alone (the others still draw their random numbers)
-eng = m.Engine(0)
-bad = 0
+HASHES = ROOT / "tests" / "golden" / "stage_a_big_campaign.json"
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-for it in range(cases):
+
+
+def winners_hash(pairs) -> str:
+    return hashlib.sha256(json.dumps([[w, int(f)] for w, f in pairs]).encode()).hexdigest()
+
+
+def draw_case(rng, it):
+    """Case `it` of the generator `rng` (every case draws its random numbers, evaluated or not)."""
     rows = int(rng.integers(150, 2500))
     L = int(rng.integers(2000, 12000))
     k = int(rng.choice([9, 11, 13, 13, 13, 15]))
@@ -49,6 +58,37 @@ for it in range(cases):
             if rng.random() < 0.2:
                 p0 = int(rng.integers(0, L)); a[p0:p0 + int(rng.integers(1, 150))] = ord("N")
         arr[r] = a
+    return arr, (seg, stride, win, k, iters, mm), dict(rows=rows, L=L, mu=mu, clades=clades)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--oracle-hashes":
+    doc = json.loads(HASHES.read_text()) if HASHES.exists() else {
+        "provenance": "tools/random_campaign_stage_a_big.py --oracle-hashes: sha256 of json.dumps([[word, frequency], ...]) of "
+                      "oracle/stage_a.c's find_candidates_kmers restatement (main.rs:331-406) per case and direction",
+        "cases": {}}
+    for seed, cases in zip(sys.argv[2::2], sys.argv[3::2]):
+        rng = np.random.default_rng(int(seed))
+        for it in range(int(cases)):
+            arr, (seg, stride, win, k, iters, mm), _ = draw_case(rng, it)
+            segs = o.Segments([bytes(r).decode() for r in arr], seg, stride, win, k)
+            doc["cases"][f"{seed}:{it}"] = [winners_hash(segs.candidates(d, iters, mm)) for d in (0, 1)]
+            print(seed, it, arr.shape, doc["cases"][f"{seed}:{it}"][0][:12], flush=True)
+    HASHES.write_text(json.dumps(doc, indent=1) + "\n")
+    sys.exit(0)
+
+import msspe_amd as m
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+rng = np.random.default_rng(seed)
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1    # evaluate this case alone (the others still draw their random numbers)
+committed = json.loads(HASHES.read_text())["cases"] if HASHES.exists() else {}
+eng = m.Engine(0)
+bad = 0
+n_hash = n_oracle = 0
+for it in range(cases):
+    arr, (seg, stride, win, k, iters, mm), meta = draw_case(rng, it)
+    rows, L, mu, clades = meta["rows"], meta["L"], meta["mu"], meta["clades"]
     opt = m.KmerOpt(seg, stride, win, k, iters, mm)
     if only >= 0 and it != only:
         continue
@@ -80,7 +120,13 @@ for it in range(cases):
                         if look in row[c0:c0 + win]:
                             cnt[part] = cnt.get(part, 0) + 1
                 print("   word", word, "partitions", cnt)
-        if (same and rows * L <= 3_000_000) or only >= 0:
+        key = f"{seed}:{it}"
+        if key in committed and only < 0:
+            # the oracle's winner sequence for this case, computed in the build container and committed
+            same = same and winners_hash(zip(w1, f1.tolist())) == committed[key][d] == winners_hash(zip(w0, f0.tolist()))
+            n_hash += 1
+        elif (same and rows * L <= 12_000_000) or only >= 0:
+            n_oracle += 1
             want = o.Segments([bytes(r).decode() for r in arr], seg, stride, win, k).candidates(d, iters, mm)
             if only >= 0:
                 print("oracle == all-words loop:", list(zip(w0, f0.tolist())) == want, " oracle == candidate-list loop:",
@@ -92,5 +138,5 @@ for it in range(cases):
     print(it, f"rows {rows} L {L} k {k} seg {seg}/{stride}/{win} iters {iters} mm {mm} mu {mu} clades {clades}", "dup" if it % 2 else "",
           "|", " ; ".join(info), ok, flush=True)
     bad += not ok
-print("BAD", bad)
+print("BAD", bad, "| directions checked against committed oracle hashes:", n_hash, "against the oracle run here:", n_oracle)
 sys.exit(1 if bad else 0)
