@@ -68,6 +68,7 @@ struct EngineOptions {
     int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
     bool row_oob = true;      // the row-specialised first stage (it reads LDS beyond its allocation: thal_pairs_row.hip) may run
     bool split_list = true;   // short oligos: tables too large for the integer list stage go to the split kernel's list mode
+    int self_lane_from = 81920;   // oligos per call from which SELF_ANY / SELF_END run one lane per oligo (msspe_oligo_stats_dev)
 };
 
 struct msspe_ctx {
@@ -376,6 +377,9 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "split_list") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->opt.split_list = num != 0;
+    } else if (k == "self_lane_from") {
+        if (!is_num || num < 0) return bad();
+        ctx->opt.self_lane_from = (int)num;
     } else if (k == "row_oob") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->opt.row_oob = num != 0;
@@ -1070,10 +1074,31 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
     if (d_tm || d_gc)
         HIP_TRY(ctx, launch_oligo_tm(d_pool, n, k, chem->dna_conc, chem->mv, chem->dv, chem->dntp,
                                      d_tm, d_gc, ctx->stream));
-    // SELF_ANY / SELF_END: one wave per oligo (thal_pairs_wave.hip); the dense kernel, one lane per
-    // oligo, only takes what that kernel leaves (self-complementary oligos, oversized tables)
+    // SELF_ANY / SELF_END (thal ANY / END1 of the oligo with itself): ONE fill of the DP serves both -- END1 is the
+    // same fillMatrix with the terminal pick restricted to the last row.  What the reference's loop
+    // produces (<= 2,000 oligos per call, main.rs:344): one wave per oligo (thal_pairs_wave.hip), whose latency is a
+    // single oligo's.  Large pools: one LANE per oligo through the f64 register-table kernels over the list of (i, i)
+    // (thal_pairs.hip, 56 then 72 slots), the wave kernel behind them for larger tables.  The dense kernel, one lane
+    // per oligo over a global workspace, takes what is left (self-complementary oligos: another RC constant).
     const bool wave_ok = !ctx->opt.force_generic && k <= ce->wave_max_k && ctx->opt.wave_kernel;
-    if (wave_ok && (rc = ensure_overflow(ctx, n))) return rc;
+    const bool lane_ok = wave_ok && n >= ctx->opt.self_lane_from && k <= pairs_fast_max_k() && ce->fast_ok &&
+                         chem->max_loop >= 2 * k - 4;
+    if (wave_ok && (d_self_any || d_self_end)) {
+        if ((rc = ensure_overflow(ctx, n))) return rc;
+        if (ctx->list_cap < n) return fail(ctx, MSSPE_ERR_NOMEM, "stage B: no memory for the work lists");
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
+        uint32_t *left = ctx->ovf_count + 3;   // entries of ovf_list2 the dense kernel has to take
+        if (lane_ok) {
+            HIP_TRY(ctx, launch_self_lists(ce->d_ft, ce->c[0], d_pool, n, k, d_self_any, d_self_end, ctx->ovf_list,
+                                           ctx->ovf_list2, ctx->ovf_count, (uint32_t)ctx->list_cap, ctx->stream));
+            HIP_TRY(ctx, launch_self_wave(ce->d_st, ce->c[0], d_pool, k, 0, n, d_self_any, d_self_end, ctx->ovf_list,
+                                          ctx->ovf_count + 2, ctx->ovf_list2, left, (uint32_t)ctx->list_cap,
+                                          ctx->ovf_count + 7, ctx->stream));
+        } else {
+            HIP_TRY(ctx, launch_self_wave(ce->d_st, ce->c[0], d_pool, k, 0, n, d_self_any, d_self_end, nullptr, nullptr,
+                                          ctx->ovf_list2, left, (uint32_t)ctx->list_cap, ctx->ovf_count + 7, ctx->stream));
+        }
+    }
     for (int pass = 0; pass < 2; ++pass) {
         double *dst = pass == 0 ? d_self_any : d_self_end;
         if (!dst) continue;
@@ -1092,15 +1117,12 @@ int msspe_oligo_stats_dev(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k,
         g.wsH = ctx->wsH;
         g.ws_lanes = kGenericLanes;
         if (wave_ok) {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
-            HIP_TRY(ctx, launch_self_wave(ce->d_st, ce->c[0], d_pool, k, 0, n, pass == 1, dst, ctx->ovf_list,
-                                          ctx->ovf_count, (uint32_t)ctx->list_cap, ctx->ovf_count + 7, ctx->stream));
-            g.list = ctx->ovf_list;
-            g.list_count = ctx->ovf_count;
+            g.list = ctx->ovf_list2;
+            g.list_count = ctx->ovf_count + 3;
         }
         HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
     }
-    if (wave_ok) HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
+    if (wave_ok && (d_self_any || d_self_end)) HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
     if (d_hairpin) {
         HairpinArgs h;
         h.tb = ctx->d_tb;

@@ -144,11 +144,19 @@ int pairs_split_lanes(int k);
 // tables) are appended to a.overflow_list for launch_dimer_generic.
 hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, const uint2 *in_list,
                              const uint32_t *in_count, hipStream_t stream);
-// Stage B on the same kernel: thal ANY / END1 of every oligo of [row0, row1) with itself, self_t[row] =
-// max(0, t); what it does not take is appended to list as (row, row).
+// Stage B on the same kernel: thal ANY and / or END1 of oligos with themselves from one fill per oligo,
+// self_any[row] / self_end[row] = max(0, t) (either may be null); the oligos are [row0, row1) or, with in_list, the
+// entries' .x; what it does not take is appended to list as (row, row).
 hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
-                            int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
-                            uint32_t list_cap, uint32_t *work_counter, hipStream_t stream);
+                            int row1, double *self_any, double *self_end, const uint2 *in_list,
+                            const uint32_t *in_count, uint2 *list, uint32_t *list_count, uint32_t list_cap,
+                            uint32_t *work_counter, hipStream_t stream);
+// Stage B for large pools, one LANE per oligo (thal_pairs.hip: the f64 register-table kernels over the list of
+// (i, i), k <= pairs_fast_max_k()): one fill, both picks.  list_a / list_b: n entries each; counters[0 .. 3).  What is
+// left (self-complementary oligos, tables beyond 72 cells) is in list_a, counters[2] entries: launch_self_wave's.
+hipError_t launch_self_lists(const FastTables *ft, const ThalConsts &c, const uint64_t *pool, int n, int k,
+                             double *self_any, double *self_end, uint2 *list_a, uint2 *list_b, uint32_t *counters,
+                             uint32_t list_cap, hipStream_t stream);
 int pairs_int_slots();
 int pairs_fast_max_k();
 // Stable grouping of the column primers by base composition (pool_sort.hip).

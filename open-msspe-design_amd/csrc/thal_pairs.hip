@@ -31,6 +31,8 @@
 //     the per-row conflict count.
 // Pairs whose DP has more complementary cells than the register table holds go to an overflow
 // list and are finished by the wide instantiation of this kernel (list mode) or the generic kernel.
+#include <cstring>
+
 #include "pair_core.hpp"
 
 namespace msspe {
@@ -235,11 +237,10 @@ __device__ __forceinline__ void store_slot(Slots<NREG, NEXT> &st, int slot, doub
 }
 
 
-// The whole thal ANY computation for the lane's pair.  n_cells == 0 means "lane idle".
+// thal.c fillMatrix() for the lane's pair: the table of all complementary cells.  n_cells == 0 means "lane idle".
 template <int NREG, int NEXT>
-__device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K, const SeqPair &q,
-                                               unsigned rowmask, int n_cells, int nmax,
-                                               Slots<NREG, NEXT> &st)
+__device__ __forceinline__ void fill_pair(const Lds &T, const ThalConsts &K, const SeqPair &q, unsigned rowmask,
+                                          int nmax, Slots<NREG, NEXT> &st)
 {
     // Every slot starts as "not computed yet": coordinates (16,16) lie beyond any cell, so such a
     // slot fails the geometry test of every cell and needs no separate mask in the scans.
@@ -309,7 +310,21 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         // ---- publish the cell (idle lanes write a slot nobody reads)
         store_slot<NREG, NEXT>(st, slot, S0, ((H0 / 10) << 14) | (b.po_c << 8) | (im1 << 4) | jm1);
     }
+}
 
+// Terminal pick, traceback and totals over a filled table.  END1 (thal type 2, libprimer3's SELF_END: only
+// structures that close on the 3' base of oligo 1, i.e. cells of the last row; without one thal() falls back to
+// cell (1, 1) and reports a structure only if that cell is a base pair) differs from ANY in the pick alone, so a
+// caller that wants both fills once and finishes twice (stage B, k_self_list).
+template <int NREG, int NEXT, bool END1 = false>
+__device__ __forceinline__ PairResult finish_pair(const Lds &T, const ThalConsts &K, const SeqPair &q, int n_cells,
+                                                  int nmax, const Slots<NREG, NEXT> &st)
+{
+    CellCtx c;
+    c.rS = 0.0;
+    c.rH = 0;
+    c.im1p = c.jm1p = 0;
+    c.yTS = c.yMM = c.bBase = 0;
     PairResult r;
     r.none = n_cells == 0;
     r.dG = INFINITY;
@@ -338,7 +353,7 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
                 const int rH = T.H[b.idxR];
                 const double rSn = rS + kTiny, rHn = (double)rH + kTiny;
                 const double Gt = (((double)H0 + rHn) + K.init_H) - kT37 * ((S[e] + rSn) + K.init_S);
-                const bool pick = (slot < n_cells) & (Gt < pickG);
+                const bool pick = (slot < n_cells) & (Gt < pickG) & (!END1 | (ci == q.len - 1));
                 pickG = pick ? Gt : pickG;
                 pickS = pick ? S[e] : pickS;
                 pickH = pick ? H0 : pickH;
@@ -351,6 +366,24 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         }
     }
 
+    if constexpr (END1) {
+        // no cell in the last row: cell (1, 1) if it is a base pair (slot 0 then, the first in row-major order)
+        double S[kChunk];
+        int W[kChunk];
+        fetch_chunk<NREG, NEXT>(st, 0, S, W);
+        const bool have = pickG < INFINITY;
+        const bool first = !have & (n_cells > 0) & ((W[0] & 0xff) == 0);
+        CellCtx dummy;
+        const CellBases b0 = cell_bases(q, 0, 0, dummy);
+        pickS = first ? S[0] : pickS;
+        pickH = first ? (W[0] >> 14) * 10 : pickH;
+        pickRS = first ? T.S[b0.idxR] : pickRS;
+        pickRH = first ? T.H[b0.idxR] : pickRH;
+        pickI = first ? 0 : pickI;
+        pickJ = first ? 0 : pickJ;
+        pickSlot = first ? 0 : pickSlot;
+        r.none = r.none | !(have | first);
+    }
     // ---- thal.c traceback(): count the base pairs of the optimal structure
     double curS = pickS;
     int curH = pickH, curI = pickI, curJ = pickJ, curSlot = pickSlot, P = 1;
@@ -388,6 +421,16 @@ __device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K
         r.conflict = G <= K.g_cut;
     }
     return r;
+}
+
+// The whole thal ANY computation for the lane's pair.
+template <int NREG, int NEXT>
+__device__ __forceinline__ PairResult run_pair(const Lds &T, const ThalConsts &K, const SeqPair &q,
+                                               unsigned rowmask, int n_cells, int nmax,
+                                               Slots<NREG, NEXT> &st)
+{
+    fill_pair<NREG, NEXT>(T, K, q, rowmask, nmax, st);
+    return finish_pair<NREG, NEXT, false>(T, K, q, n_cells, nmax, st);
 }
 
 __device__ __forceinline__ void load_tables(Lds &T, const FastTables *ft)
@@ -464,8 +507,11 @@ __global__ void __launch_bounds__(256, WAVES) k_pairs_fast(FastArgs a)
 
 // List mode: lane = one explicit pair (the list a previous stage left behind).  THREADS-wide
 // blocks: 40 register slots + NEXT * 8 LDS slots per lane, two blocks per CU.
-template <int NREG, int NEXT, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs a)
+// SELF (stage B, od-msspe/src/primer.rs:143-166: PRIMER_LEFT_0_SELF_ANY_TH / SELF_END_TH of libprimer3's
+// oligo_compl_thermod): the entries are (i, i); ONE fill serves thal ANY and thal END1, each finished on its own
+// (finish_pair), self_any[i] / self_end[i] = max(0, t) (either may be null).
+template <int NREG, int NEXT, int THREADS, bool SELF>
+__device__ __forceinline__ void list_body(const FastArgs &a, double *self_any, double *self_end)
 {
     struct Shared {
         Lds T;
@@ -473,6 +519,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
     };
     __shared__ Shared sh;
     Lds &T = sh.T;
+    if (*a.in_count == 0u) return;   // an empty list: no table loads
     load_tables(T, a.ft);
     Slots<NREG, NEXT> st;
     st.xS = &sh.X.S[0][threadIdx.x];
@@ -488,8 +535,11 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
                   "the slot extension must hold one sorted batch");
     uint2 *sorted = reinterpret_cast<uint2 *>(&sh.X);
     unsigned *hist = reinterpret_cast<unsigned *>(sorted + kListBatch * THREADS);
-    const long n_work = (long)min(*a.in_count, a.ovf_cap);
-    const long batch = (long)kListBatch * THREADS;
+    const long n_work = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)min(*a.in_count, a.ovf_cap));
+    // a short list is spread over the blocks (one pass each) instead of being run four passes deep by a few of them
+    const long per_pass = (long)gridDim.x * THREADS;
+    const int depth = (int)min((long)kListBatch, max(1L, (n_work + per_pass - 1) / per_pass));
+    const long batch = (long)depth * THREADS;
     const long n_batches = (n_work + batch - 1) / batch;
     for (long bt = blockIdx.x; bt < n_batches; bt += gridDim.x) {
         // ---- 1. keys and histogram
@@ -501,7 +551,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
 #pragma unroll
         for (int j = 0; j < kListBatch; ++j) {
             const long w = bt * batch + (long)j * THREADS + threadIdx.x;
-            const bool inside = w < n_work;
+            const bool inside = (j < depth) & (w < n_work);   // passes beyond the depth hold padding only
             mine[j] = inside ? a.in_list[w] : make_uint2(0xffffffffu, 0u);
             int nc = 255;   // padding entries sort last
             if (inside) {
@@ -549,7 +599,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
         }
         __syncthreads();   // the extension is the DP's again; the writes are visible to the block
         // ---- 4. the pairs
-        for (int j = 0; j < kListBatch; ++j) {
+        for (int j = 0; j < depth; ++j) {
             const long e = (long)j * THREADS + threadIdx.x;
             const bool inside = e < n_own;
             uint2 pr = own[inside ? e : 0];
@@ -567,6 +617,18 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
             if (!inside | spill) n_cells = 0;
             const int nmax = wave_max(n_cells);
             if (nmax == 0) continue;   // wave-uniform: nothing but padding / handed-on pairs
+            if constexpr (SELF) {
+                fill_pair<NREG, NEXT>(T, a.c, q, rowmask, nmax, st);
+                if (self_any) {   // kernel argument: uniform
+                    const PairResult r = finish_pair<NREG, NEXT, false>(T, a.c, q, n_cells, nmax, st);
+                    if (inside & !spill) self_any[pr.x] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
+                }
+                if (self_end) {
+                    const PairResult r = finish_pair<NREG, NEXT, true>(T, a.c, q, n_cells, nmax, st);
+                    if (inside & !spill) self_end[pr.x] = (r.none || r.t < 0.0) ? 0.0 : r.t;
+                }
+                continue;
+            }
             const PairResult r = run_pair<NREG, NEXT>(T, a.c, q, rowmask, n_cells, nmax, st);
             if (inside & !spill) {
                 const size_t orow = (size_t)((int)pr.x - a.sinks.row0);
@@ -584,6 +646,26 @@ __global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs 
         }
         __syncthreads();   // before the next batch reuses the scratch
     }
+}
+
+template <int NREG, int NEXT, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 128) k_pairs_list(FastArgs a)
+{
+    list_body<NREG, NEXT, THREADS, false>(a, nullptr, nullptr);
+}
+
+template <int NREG, int NEXT, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS / 128) k_self_list(FastArgs a, double *self_any, double *self_end)
+{
+    list_body<NREG, NEXT, THREADS, true>(a, self_any, self_end);
+}
+
+// stage B's work list: entry i = (i, i)
+__global__ void k_self_entries(uint2 *list, uint32_t *count, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) list[i] = make_uint2((unsigned)i, (unsigned)i);
+    if (i == 0) *count = (uint32_t)n;
 }
 
 constexpr int kNregMain = 5;   // 40 slots in VGPRs ...
@@ -655,6 +737,34 @@ hipError_t launch_pairs_main_list(const PairKernelArgs &a, const uint2 *in_list,
 {
     const FastArgs f = list_args(a, in_list, in_count);
     hipLaunchKernelGGL((k_pairs_list<kNregMain, kNextMain, 256>), dim3(256 * 2), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+
+// Stage B, one lane per oligo: the f64 register-table kernels over the list of (i, i), n oligos.  list_a / list_b:
+// two lists of at least n entries, counters[0 .. 3): device words (zeroed here).  What is left -- self-complementary
+// oligos, tables beyond 72 cells -- ends up in list_a with counters[2] entries, for launch_self_wave.
+hipError_t launch_self_lists(const FastTables *ft, const ThalConsts &c, const uint64_t *pool, int n, int k,
+                             double *self_any, double *self_end, uint2 *list_a, uint2 *list_b, uint32_t *counters,
+                             uint32_t list_cap, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    if (hipError_t e = hipMemsetAsync(counters, 0, 3 * sizeof(uint32_t), stream); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_self_entries, dim3((n + 255) / 256), dim3(256), 0, stream, list_a, counters, n);
+    PairKernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.ft = ft;
+    a.c = c;
+    a.pool = pool;
+    a.k = k;
+    a.overflow_cap = list_cap;
+    a.overflow_list = list_b;
+    a.overflow_count = counters + 1;
+    FastArgs f = list_args(a, list_a, counters);
+    hipLaunchKernelGGL((k_self_list<kNregMain, kNextMain, 256>), dim3(256 * 2), dim3(256), 0, stream, f, self_any, self_end);
+    a.overflow_list = list_a;
+    a.overflow_count = counters + 2;
+    f = list_args(a, list_b, counters + 1);
+    hipLaunchKernelGGL((k_self_list<kNregWide, kNextWide, 128>), dim3(256 * 4), dim3(128), 0, stream, f, self_any, self_end);
     return hipGetLastError();
 }
 

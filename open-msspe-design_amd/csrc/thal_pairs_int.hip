@@ -645,13 +645,20 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
 {
     typedef SharedI<kSlotsList, kThreadsI, IntTables::kRows> SH;
     __shared__ SH sh;
+    if (*a.f.in_count == 0u) return;   // an empty list: no table loads
     load_tables_int(sh, a);
     static_assert(sizeof(sh.pred) >= sizeof(uint2) * kListBatchI * kThreadsI + sizeof(unsigned) * 256,
                   "the predecessor rows must hold one sorted batch");
     uint2 *sorted = reinterpret_cast<uint2 *>(&sh.pred[0][0]);
     unsigned *hist = reinterpret_cast<unsigned *>(sorted + kListBatchI * kThreadsI);
     const long n_work = (long)min(*a.f.in_count, a.f.ovf_cap);
-    const long batch = (long)kListBatchI * kThreadsI;
+    // A batch is `depth` x 512 entries, sorted together and run as `depth` lock-step passes.  Long lists take the
+    // full depth (better sorted lanes); a short list -- the screen of a reference-sized pool hands on some ten
+    // thousand pairs -- is spread over all the blocks instead of keeping two dozen of them busy for seven passes
+    // (2,000 primers: 2.30 ms -> one pass).  Which pairs the stage answers does not depend on the depth.
+    const long per_pass = (long)gridDim.x * kThreadsI;
+    const int depth = (int)min((long)kListBatchI, max(1L, (n_work + per_pass - 1) / per_pass));
+    const long batch = (long)depth * kThreadsI;
     const long n_batches = (n_work + batch - 1) / batch;
     __shared__ unsigned next_batch;
     for (;;) {
@@ -667,7 +674,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
 #pragma unroll
         for (int j = 0; j < kListBatchI; ++j) {
             const long w = bt * batch + (long)j * kThreadsI + threadIdx.x;
-            const bool inside = w < n_work;
+            const bool inside = (j < depth) & (w < n_work);   // passes beyond the depth hold padding only
             mine[j] = inside ? a.f.in_list[w] : make_uint2(0xffffffffu, 0u);
             int nc = 255;   // padding sorts last
             if (inside) {
@@ -710,7 +717,7 @@ __global__ void __launch_bounds__(kThreadsI) k_pairs_int_list(IntArgs a)
             if (e < n_own) own[e] = sorted[e];
         }
         __syncthreads();   // the predecessor rows are the DP's again; the writes are visible to the block
-        for (int j = 0; j < kListBatchI; ++j) {
+        for (int j = 0; j < depth; ++j) {
             const long e = (long)j * kThreadsI + threadIdx.x;
             const bool inside = e < n_own;
             const uint2 pr = own[inside ? e : 0];

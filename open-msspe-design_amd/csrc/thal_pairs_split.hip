@@ -485,6 +485,7 @@ template <int Q, bool LIST>
 __global__ void __launch_bounds__(kThreadsS) k_pairs_split(SplitArgs a)
 {
     __shared__ SharedS sh;
+    if (LIST && *a.in_count == 0u) return;   // nothing was handed on: not worth 53 KB of table loads per block
     load_tables_s(sh, a);
     constexpr int kPairsPerWave = 64 / Q;
     const int lane = threadIdx.x & 63;

@@ -53,10 +53,10 @@ struct WaveArgs {
     uint2 *ovf_list;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
-    // self mode (stage B, libprimer3 align_thermod of an oligo with itself): work item w = pair
-    // (row0 + w, row0 + w), result self_t[row] = max(0, t); end1: thal END1 instead of ANY
-    double *self_t;
-    int end1;
+    // self mode (stage B, libprimer3 align_thermod of an oligo with itself; on when self_any or self_end is
+    // set): work item w = pair (row0 + w, row0 + w), or (in_list[w].x, in_list[w].x) with a list; ONE fill,
+    // then thal ANY -> self_any[row] = max(0, t) and thal END1 -> self_end[row] (either may be null)
+    double *self_any, *self_end;
     unsigned *work_counter;          // next work item, zero at launch
 };
 
@@ -111,23 +111,18 @@ __device__ __forceinline__ CandW candidate(const SharedWv &sh, const CellS &b, i
     return r;
 }
 
-// thal ANY for one pair, computed by the whole wave.  Returns false when the pair does not fit.
-__device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint64_t pa, uint64_t pb, int k,
-                              bool end1, WaveResult &out)
+// thal.c fillMatrix() for one pair, computed by the whole wave: the cells' values in the wave's LDS table.
+// Returns the number of cells, or -1 when the pair does not fit the table.
+__device__ int fill_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint64_t pa, uint64_t pb, int k, SeqW &q)
 {
     const int lane = threadIdx.x & 63;
     double *cS = sh.cS[wave];
     int *cH = sh.cH[wave];
     unsigned short *cW = sh.cW[wave];
-    SeqW q;
     unsigned long long rowmask;
     const int n = setup_pair_w(pa, pb, k, q, rowmask);
-    out.none = n == 0;
-    out.dG = INFINITY;
-    out.t = 0.0;
-    out.conflict = false;
-    if (n > kWaveCells) return false;
-    if (n == 0) return true;
+    if (n > kWaveCells) return -1;
+    if (n == 0) return 0;
     // ---- the cells in row-major order: lane = row, exclusive scan of the row lengths
     {
         unsigned long long m = 0ull;
@@ -206,6 +201,22 @@ __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint6
         }
         __builtin_amdgcn_wave_barrier();
     }
+    return n;
+}
+
+// Terminal pick (thal ANY, or END1: the last row only), thal.c's value-matching traceback and the totals over a
+// filled table of n > 0 cells.
+__device__ void finish_pair_wave(const SharedWv &sh, int wave, const ThalConsts &K, const SeqW &q, int k, int n, bool end1,
+                                 WaveResult &out)
+{
+    const int lane = threadIdx.x & 63;
+    const double *cS = sh.cS[wave];
+    const int *cH = sh.cH[wave];
+    const unsigned short *cW = sh.cW[wave];
+    out.none = false;
+    out.dG = INFINITY;
+    out.t = 0.0;
+    out.conflict = false;
     // ---- terminal pick: strict minimum of the nudged dG, first in row-major order
     double pickG = INFINITY;
     int pickSlot = 0x7fffffff;
@@ -229,7 +240,7 @@ __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint6
         // is a base pair (only reachable in END1 mode, where the last row may hold no cell)
         if ((cW[0] & 0x3ff) != 0) {
             out.none = true;
-            return true;
+            return;
         }
         pickSlot = 0;
     }
@@ -280,8 +291,6 @@ __device__ bool run_pair_wave(SharedWv &sh, int wave, const ThalConsts &K, uint6
         out.dG = dH - (K.temp_k * (dS + (N * K.salt)));
         out.conflict = out.dG <= K.g_cut;
     }
-    __builtin_amdgcn_wave_barrier();
-    return true;
 }
 
 __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
@@ -294,8 +303,9 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long ncols = a.col1 - a.col0;
-    const long n_work = a.self_t ? (long)(a.row1 - a.row0)
-                                 : (a.in_list ? (long)min(*a.in_count, a.in_cap) : (long)(a.row1 - a.row0) * ncols);
+    const bool self = a.self_any || a.self_end;
+    const long n_work = a.in_list ? (long)min(*a.in_count, a.in_cap)
+                                  : (self ? (long)(a.row1 - a.row0) : (long)(a.row1 - a.row0) * ncols);
     for (;;) {
         // pairs are handed to the waves from a counter: their cost ranges over an order of magnitude
         unsigned next = 0;
@@ -303,12 +313,12 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
         const long w = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)next);
         if (w >= n_work) break;   // wave-uniform
         int row, col;
-        if (a.self_t) {
-            row = col = a.row0 + (int)w;
-        } else if (a.in_list) {
+        if (a.in_list) {
             const uint2 pr = a.in_list[w];
             row = (int)(pr.x & 0x7fffffffu);
-            col = (int)pr.y;
+            col = self ? row : (int)pr.y;
+        } else if (self) {
+            row = col = a.row0 + (int)w;
         } else {
             row = a.row0 + (int)(w / ncols);
             col = a.col0 + (int)(w % ncols);
@@ -320,15 +330,23 @@ __global__ void __launch_bounds__(kThreadsW) k_pairs_wave(WaveArgs a)
         r.conflict = false;
         r.dG = INFINITY;
         r.t = 0.0;
-        const bool fits = !sym && run_pair_wave(sh, wave, a.c, pa, pb, a.k, a.end1 != 0, r);
+        SeqW q;
+        const int n_cells = sym ? -1 : fill_pair_wave(sh, wave, a.c, pa, pb, a.k, q);   // wave-uniform
+        const bool fits = n_cells >= 0;
+        WaveResult r_end = r;
+        if (n_cells > 0) {
+            if (!self || a.self_any) finish_pair_wave(sh, wave, a.c, q, a.k, n_cells, false, r);
+            if (self && a.self_end) finish_pair_wave(sh, wave, a.c, q, a.k, n_cells, true, r_end);
+        }
         // lane 0 reports; no lane may run ahead into the next fetch (readfirstlane reads the first
         // ACTIVE lane), so there is no early `continue` here: the wave reconverges at the loop's end
         if (lane == 0) {
             if (!fits) {
                 const uint32_t at = atomicAdd(a.ovf_count, 1u);
                 if (at < a.ovf_cap) a.ovf_list[at] = make_uint2((unsigned)row, (unsigned)col);
-            } else if (a.self_t) {
-                a.self_t[row] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
+            } else if (self) {
+                if (a.self_any) a.self_any[row] = (r.none || r.t < 0.0) ? 0.0 : r.t;   // libprimer3 align_thermod()
+                if (a.self_end) a.self_end[row] = (r_end.none || r_end.t < 0.0) ? 0.0 : r_end.t;
             } else {
                 const size_t orow = (size_t)(row - a.sinks.row0);
                 const size_t ocol = (size_t)(col - a.sinks.col0);
@@ -369,8 +387,7 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
     x.ovf_list = a.overflow_list;
     x.ovf_count = a.overflow_count;
     x.ovf_cap = a.overflow_cap;
-    x.self_t = nullptr;
-    x.end1 = 0;
+    x.self_any = x.self_end = nullptr;
     x.work_counter = a.work_counter;
     if (!in_list && ((long)(a.row1 - a.row0) * (long)(a.col1 - a.col0) <= 0)) return hipSuccess;
     if (hipError_t e = hipMemsetAsync(a.work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
@@ -378,12 +395,14 @@ hipError_t launch_pairs_wave(const PairKernelArgs &a, const SplitTables *st, con
     return hipGetLastError();
 }
 
-// Stage B: thal ANY (end1 = false) or END1 of every oligo of [row0, row1) with itself, self_t[row] =
-// max(0, t).  Oligos it does not take (self-complementary ones, oversized tables) are appended to
-// list as (row, row) for launch_dimer_generic.
+// Stage B: thal ANY and / or thal END1 of oligos with themselves from ONE fill per oligo, self_any[row] /
+// self_end[row] = max(0, t) (either may be null).  The oligos: [row0, row1) of the pool, or -- in_list set -- the
+// entries' .x (what launch_self_lists left over).  Oligos it does not take (self-complementary ones, oversized
+// tables) are appended to list as (row, row) for launch_dimer_generic.
 hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const uint64_t *pool, int k, int row0,
-                            int row1, bool end1, double *self_t, uint2 *list, uint32_t *list_count,
-                            uint32_t list_cap, uint32_t *work_counter, hipStream_t stream)
+                            int row1, double *self_any, double *self_end, const uint2 *in_list,
+                            const uint32_t *in_count, uint2 *list, uint32_t *list_count, uint32_t list_cap,
+                            uint32_t *work_counter, hipStream_t stream)
 {
     WaveArgs x;
     std::memset(&x, 0, sizeof x);
@@ -395,15 +414,18 @@ hipError_t launch_self_wave(const SplitTables *st, const ThalConsts &c, const ui
     x.row1 = row1;
     x.col0 = 0;
     x.col1 = 1;
+    x.in_list = in_list;
+    x.in_count = in_count;
+    x.in_cap = list_cap;
     x.ovf_list = list;
     x.ovf_count = list_count;
     x.ovf_cap = list_cap;
-    x.self_t = self_t;
-    x.end1 = end1 ? 1 : 0;
+    x.self_any = self_any;
+    x.self_end = self_end;
     x.work_counter = work_counter;
-    if (row1 <= row0) return hipSuccess;
+    if ((!self_any && !self_end) || (!in_list && row1 <= row0)) return hipSuccess;
     if (hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(unsigned), stream); e != hipSuccess) return e;
-    const int blocks = (row1 - row0 + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int blocks = in_list ? 512 : (row1 - row0 + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(k_pairs_wave, dim3(blocks < 512 ? blocks : 512), dim3(kThreadsW), 0, stream, x);
     return hipGetLastError();
 }

@@ -137,8 +137,19 @@ def test_a_resolved_pick_whose_walks_meet_a_tie_stays_open(eng, m, oracle, oracl
             eng.set_option("pair_kernel", "auto")
 
 
-def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
-    """primer3_core view (od-msspe/src/primer.rs:143-166): Tm, GC%, SELF_ANY/END, HAIRPIN."""
+@pytest.mark.parametrize("lane_from", [None, 0])
+def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir, lane_from):
+    """primer3_core view (od-msspe/src/primer.rs:143-166): Tm, GC%, SELF_ANY/END, HAIRPIN.  lane_from = 0: the
+    self-dimers through the one-lane-per-oligo kernels large pools take (one fill, ANY and END1 picks)."""
+    if lane_from is not None:
+        eng.set_option("self_lane_from", lane_from)
+    try:
+        _oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir)
+    finally:
+        eng.set_option("self_lane_from", 81920)
+
+
+def _oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
     pool = m.synth.pool_strings(m.synth.random_pool(300, 13, seed=9))
     pool += ["AGCCCGTGTAAAC", "ACGTGAAAACGTA", "GCGCTTTTGCGCA", "GGGGCCCTTTGGG", "ATATATATATATA",
              "GGGGGGGCCCCCC", "AAAAAAAAAAAAA", "CCCGGGAAACCCG",
@@ -156,6 +167,53 @@ def test_oligo_stats_bit_exact(eng, m, oracle, oracle_tables, golden_dir):
     assert m.round_fixed_f32(got["gc"][i], 3) == np.float32(g["gc"])
     assert got["self_any"][i] == 0.0 and got["self_end"][i] == 0.0 and got["hairpin"][i] == 0.0
     assert (got["hairpin"] > 0).sum() >= 3 and (got["self_any"] > 0).sum() >= 3
+
+
+@pytest.mark.parametrize("k,n,lane_from", [(13, 90000, None), (16, 33000, 0), (9, 35000, 0)])
+def test_self_dimers_of_a_large_pool_one_lane_per_oligo(eng, m, oracle, oracle_tables, k, n, lane_from):
+    """From 81,920 oligos per call (option self_lane_from) SELF_ANY / SELF_END run one lane per oligo (f64 register
+    tables, 56 then 72 slots, the wave kernel and the dense kernel behind them): same doubles as the oracle, whichever
+    of the two is asked for, and as the one-wave-per-oligo path."""
+    import torch
+    if lane_from is not None:
+        eng.set_option("self_lane_from", lane_from)
+    rng = np.random.default_rng(k * 1000 + 7)
+    pool = m.synth.random_pool(n, k, seed=77 + k)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    for j in range(0, n, 17):            # self-complementary oligos (dense kernel) and near-palindromes (large tables)
+        half = pool[j, :k // 2].copy()
+        pool[j, k - k // 2:] = np.array([comp[c] for c in half[::-1]], dtype=np.uint8)
+    pool[5] = np.frombuffer(b"ATATATATATATATATAT"[:k], dtype=np.uint8)       # tables beyond 72 cells
+    pool[6] = np.frombuffer(b"GCGCGCGCGCGCGCGCGC"[:k], dtype=np.uint8)
+    pool[7] = np.frombuffer(b"AAAAAAAAAAAAAAAAAC"[-k:], dtype=np.uint8)      # END1: empty last row
+    words = m.synth.pool_strings(pool)
+    ref = oracle.check_primers(oracle_tables, words)
+    got = eng.oligo_stats(words)
+    np.testing.assert_array_equal(got["self_any"], ref["self_any_th"])
+    np.testing.assert_array_equal(got["self_end"], ref["self_end_th"])
+    assert (got["self_any"] > 0).sum() > n // 100 and (got["self_end"] > 0).sum() > n // 200
+    # each statistic asked for alone (one finish per fill), on the device-pointer entry point
+    d_pool = torch.from_numpy(m.pack_oligos(pool).view(np.int64)).cuda()
+    d_out = torch.full((2, n), -1.0, dtype=torch.float64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng.oligo_stats_dev(d_pool.data_ptr(), n, k, m.Chem.primer3(), d_self_any=d_out[0].data_ptr())
+        eng.oligo_stats_dev(d_pool.data_ptr(), n, k, m.Chem.primer3(), d_self_end=d_out[1].data_ptr())
+        torch.cuda.synchronize()
+        alone = d_out.cpu().numpy()
+        np.testing.assert_array_equal(alone[0], ref["self_any_th"])
+        np.testing.assert_array_equal(alone[1], ref["self_end_th"])
+        eng.set_option("self_lane_from", 1 << 30)            # the one-wave-per-oligo path on the same pool
+        d_out.fill_(-1.0)
+        eng.oligo_stats_dev(d_pool.data_ptr(), n, k, m.Chem.primer3(), d_self_any=d_out[0].data_ptr(),
+                            d_self_end=d_out[1].data_ptr())
+        torch.cuda.synchronize()
+        wave = d_out.cpu().numpy()
+        np.testing.assert_array_equal(wave[0], ref["self_any_th"])
+        np.testing.assert_array_equal(wave[1], ref["self_end_th"])
+    finally:
+        eng.set_option("self_lane_from", 81920)
+        eng.reset_stream()
 
 
 def test_oligo_stats_longer_oligos(eng, m, oracle, oracle_tables):

@@ -22,7 +22,7 @@ d_pool = torch.from_numpy(m.pack_oligos(pool).view(np.int64)).cuda()
 d_out = torch.zeros((5, n), dtype=torch.float64, device="cuda")
 ptr = [d_out[q].data_ptr() for q in range(5)]
 parts = {"tm_gc": (ptr[0], ptr[1], 0, 0, 0), "self_any": (0, 0, ptr[2], 0, 0), "self_end": (0, 0, 0, ptr[3], 0),
-         "hairpin": (0, 0, 0, 0, ptr[4])}
+         "self_dimers": (0, 0, ptr[2], ptr[3], 0), "hairpin": (0, 0, 0, 0, ptr[4]), "all": tuple(ptr)}
 chem = m.Chem.primer3()
 for name, a in parts.items():
     eng.oligo_stats_dev(d_pool.data_ptr(), n, k, chem, *a)
@@ -33,5 +33,5 @@ for name, a in parts.items():
         eng.oligo_stats_dev(d_pool.data_ptr(), n, k, chem, *a)
     e1.record()
     torch.cuda.synchronize()
-    print(f"{name:9s} n={n} k={k}: {e0.elapsed_time(e1) / 3:.3f} ms", flush=True)
+    print(f"{name:11s} n={n} k={k}: {e0.elapsed_time(e1) / 3:.3f} ms", flush=True)
 print("hairpin > 0:", int((d_out[4] > 0).sum().item()), "of", n)

@@ -6,7 +6,7 @@ ancestors), gaps and N runs.  The candidate-list loop against the all-words loop
 loop, itself checked against the oracle by the other campaign), both directions, whole winner sequences with their
 frequencies; AND against the oracle: through the committed hashes of the oracle's winner sequences where
 tests/golden/stage_a_big_campaign.json holds the case (the fixed-seed cases the suite runs), else by running the oracle
-beside the GPU where the case is affordable (rows x L <= 12,000,000).
+beside the GPU where the case is affordable (every case this generator draws: rows x L <= 30,000,000, seconds each).
 usage: random_campaign_stage_a_big.py [seed] [cases] [only]                 (GPU)
        random_campaign_stage_a_big.py --oracle-hashes seed cases [seed cases ...]   (build container, no GPU: writes
                                                                                     the hashes of every case)"""
@@ -125,7 +125,7 @@ for it in range(cases):
             # the oracle's winner sequence for this case, computed in the build container and committed
             same = same and winners_hash(zip(w1, f1.tolist())) == committed[key][d] == winners_hash(zip(w0, f0.tolist()))
             n_hash += 1
-        elif (same and rows * L <= 12_000_000) or only >= 0:
+        elif (same and rows * L <= 40_000_000) or only >= 0:
             n_oracle += 1
             want = o.Segments([bytes(r).decode() for r in arr], seg, stride, win, k).candidates(d, iters, mm)
             if only >= 0:

@@ -30,6 +30,9 @@ for it in range(cases):
             s = pool[j][:stem]
             loop = pool[j][stem:k - stem]
             pool[j] = s + loop + "".join(comp[c] for c in reversed(s))
+    # every other case: the self-dimers through the one-lane-per-oligo kernels of large pools (k <= 16; longer oligos
+    # stay on the wave kernel whatever the option says)
+    eng.set_option("self_lane_from", 0 if it % 2 else 81920)
     got = eng.oligo_stats(pool)
     ref = o.check_primers(tabs, pool)
     ok = [np.array_equal(got["tm"], ref["tm"]), np.array_equal(got["gc"], ref["gc"]),
