@@ -64,9 +64,14 @@ def parse_args():
                     help="also time stage B (Tm / GC / SELF_ANY / SELF_END / HAIRPIN) on 2,000 and 1,048,576 oligos "
                          "(default: on at N = 1)")
     ap.add_argument("--no-stage-b", dest="stage_b", action="store_false")
-    ap.add_argument("--max-seconds", type=float, default=600.0,
-                    help="--config pool1m only: the timed region's budget; the step count is cut to fit it "
-                         "(one step is 1.1e12 checks: about 9 minutes on one GPU, about 70 s on eight)")
+    ap.add_argument("--max-seconds", type=float, default=450.0,
+                    help="--config pool1m only: budget of the WHOLE run after start-up (estimate pass + warm-up + timed "
+                         "region + CPU leg); the step counts are cut to fit it, never below one timed step "
+                         "(one step is 1.1e12 checks: about 8 minutes on one GPU, about a minute on eight)")
+    ap.add_argument("--small-pool", dest="small_pool", action="store_true", default=None,
+                    help="also time the reference-sized screens: 2,000 random 13-mers and the stage-A winners of the "
+                         "10,000-genome alignment (default: on at N = 1)")
+    ap.add_argument("--no-small-pool", dest="small_pool", action="store_false")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -139,27 +144,38 @@ def stage_a_line(eng, device):
     form (2-bit bases + validity bit: what msspe_device_put_rows_packed leaves there).  Algorithmic bytes per
     direction: the windows' packed bits read (50 columns x 3 bits per segment), 38 keys x 4 B
     written, sorted with their 4-byte instance numbers and indexed once (post + word ids: 38 x 8 B), 38 x 4 B
-    of count updates when the segment is covered."""
+    of count updates when the segment is covered (931 B per segment; rounds 1 and 2 priced 708 B: their JSON lines are
+    not comparable in GB/s).  Returns (line, winners of the two directions)."""
     n_rows, length = 10000, 30000
     genomes = msspe_amd.synth.aligned_genomes(n_rows, length)
     d = eng.put_rows_packed(genomes)
     opt = msspe_amd.KmerOpt(500, 250, 50, K, 1000, 10)
     out = {}
+    words = {0: [], 1: []}
     try:
         for direction in (0, 1):
             eng.kmer_candidates_packed(d, n_rows, length, opt, direction)
         torch.cuda.synchronize()
         reps = 3
-        t0 = time.perf_counter()
         winners = 0
         its = np.zeros(4)
+        ev_ms = []
+        t0 = time.perf_counter()
         for _ in range(reps):
             for direction in (0, 1):
+                # two events on the engine's stream around ONE direction: the device-side span of the call, the loop's
+                # host round trips included (the call returns with the winners on the host)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 w, _f = eng.kmer_candidates_packed(d, n_rows, length, opt, direction)
+                e1.record()
+                ev_ms.append((e0, e1))
                 winners += len(w)
+                words[direction] = w
                 its += [eng.info("stage_a_" + x) for x in ("fast_iterations", "general_iterations", "rebuilds", "idle_iterations")]
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / (2 * reps) * 1e3
+        ev = float(np.mean([a.elapsed_time(b) for a, b in ev_ms]))
     finally:
         eng.device_free(d)
     segments = n_rows * ((length - 500) // 250 + 1)
@@ -168,27 +184,35 @@ def stage_a_line(eng, device):
     out.update({"workload": f"{n_rows} synthetic aligned genomes x {length} columns (packed), k = {K}, both directions",
                 "ms_per_direction": ms, "winners_per_direction": winners / (2 * reps),
                 "greedy_iterations_per_direction": {"from_partition_leaders": its[0], "after_posting_walks": its[1],
-                                                    "candidate_lists_made": its[2]},
+                                                    "candidate_lists_made": its[2], "idle": its[3]},
                 "algorithmic_bytes_per_direction": alg_bytes,
+                "algorithmic_bytes_per_segment": alg_bytes / segments,
                 "GBps": alg_bytes / (ms * 1e-3) / 1e9,
                 "frac_of_6.29TBps_copy_ceiling": alg_bytes / (ms * 1e-3) / 6.29e12,
-                "note": "host wall time per direction incl. the greedy loop's dependent launches and its host "
-                        "round trips; per-kernel times: profiles/r03_stage_a_kernel_stats.csv, DESIGN.md 4.3"})
+                "note": "ms_per_direction: host wall time per direction incl. the greedy loop's dependent launches and "
+                        "its host round trips"})
+    # measured in THIS run: algorithmic bytes / the events' span of one direction, against the measured-copy ceiling
+    out["roofline"] = {"bound": "hbm", "achieved": alg_bytes / (ev * 1e-3) / 1e9, "peak": 6290.0, "unit": "GB/s",
+                       "frac": alg_bytes / (ev * 1e-3) / 6.29e12, "event_ms_per_direction": ev,
+                       "source": "live: HIP events on the engine's stream around each direction, mean of %d" % len(ev_ms)}
     roof = stage_a_kernel_roofline(alg_bytes)
     if roof:
-        out["roofline"] = roof
-    return out
+        out["roofline_sum_of_kernels"] = roof
+    return out, words
 
 
 def stage_a_kernel_roofline(alg_bytes: float):
-    """bytes / SUM of kernel time per direction, from the committed rocprofv3 summary of the same workload
+    """bytes / SUM of kernel time per direction, from the newest committed rocprofv3 summary of the same workload
     (tools/perf_stage_a.py 10000 30000 under --kernel-trace --stats: two directions x two repetitions; the packing of
-    byte rows, which the packed entry point does not run, and the engine's one-off LDS probe are left out).  Imported,
-    and labelled so: bench.py cannot see kernel times of this many small launches without the profiler."""
+    byte rows, which the packed entry point does not run, and the engine's one-off LDS probe are left out).  IMPORTED,
+    and labelled so -- bench.py cannot see kernel times of this many small launches without the profiler; the figure
+    measured in this run is stage_a.roofline.  The summary's side file names the commit it was taken at."""
     import csv
-    path = Path(__file__).resolve().parent / "profiles" / "r03_stage_a_kernel_stats.csv"
-    if not path.exists():
+    prof = Path(__file__).resolve().parent / "profiles"
+    cands = sorted(prof.glob("r*_stage_a_kernel_stats.csv"))
+    if not cands:
         return None
+    path = cands[-1]
     total_ns = 0.0
     for row in csv.DictReader(open(path)):
         name = row["Name"]
@@ -196,9 +220,73 @@ def stage_a_kernel_roofline(alg_bytes: float):
             continue
         total_ns += float(row["TotalDurationNs"])
     ms = total_ns / 4 / 1e6
+    commit = None
+    side = path.with_suffix(".commit")
+    if side.exists():
+        commit = side.read_text().strip()
     return {"bound": "hbm", "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": 6290.0, "unit": "GB/s",
-            "frac": alg_bytes / (ms * 1e-3) / 6.29e12, "kernel_ms_per_direction": ms,
-            "source": "profiles/r03_stage_a_kernel_stats.csv (imported: rocprofv3 kernel times of the same workload)"}
+            "frac": alg_bytes / (ms * 1e-3) / 6.29e12, "kernel_ms_per_direction": ms, "profiled_commit": commit,
+            "source": f"profiles/{path.name} (imported: rocprofv3 kernel times of the same workload, not this run)"}
+
+
+def small_pool_line(eng, device, winners):
+    """The screens the reference really runs: od-msspe caps candidates at 1,000 per direction (main.rs:344), so its
+    stage-C matrix is at most 2,000^2.  Two pools, resident in HBM, counts + bitmap: 2,000 random 13-mers (SURVEY.md
+    8d) and the actual stage-A winners of the 10,000-genome alignment (both directions).  ms per FULL screen from HIP
+    events on the engine's stream (composition sort, first stage, every list stage and the flush inside), the CPU
+    restatement on the same pool beside it, every decision compared."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import pyoracle
+    tables = pyoracle.Tables()
+    chem = msspe_amd.Chem.ntthal()
+    pools = {"random_2000": msspe_amd.synth.random_pool(2000, K)}
+    if winners and (winners[0] or winners[1]):
+        w = list(winners[0]) + list(winners[1])
+        pools["stage_a_winners"] = np.frombuffer("".join(w).encode(), dtype=np.uint8).reshape(len(w), K)
+    out = {"chemistry": "od-msspe defaults (mv 50, dv 3, dNTP 0, 250 nM, 25 C), threshold -9000 cal/mol", "pools": {}}
+    cores = min(os.cpu_count() or 1, 16)
+    for name, pool_ascii in pools.items():
+        n = pool_ascii.shape[0]
+        words = (n + 63) // 64
+        d_pool = torch.from_numpy(msspe_amd.pack_oligos(pool_ascii).view(np.int64)).to(device)
+        d_rc = torch.zeros(n, dtype=torch.int32, device=device)
+        d_bm = torch.zeros((n, words), dtype=torch.int64, device=device)
+
+        def screen():
+            d_rc.zero_()
+            eng.cross_dimer_dev(d_pool.data_ptr(), n, K, chem, THRESHOLD, (0, n), (0, n), d_rc.data_ptr(), d_bm.data_ptr())
+        for _ in range(3):
+            screen()
+        torch.cuda.synchronize()
+        eng.last_overflow_pairs()
+        eng.profile_enable(True)
+        reps = 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            screen()
+        e1.record()
+        torch.cuda.synchronize()
+        launches, kernel_ms = eng.profile_read()
+        eng.profile_enable(False)
+        handed = eng.last_overflow_pairs() / reps
+        ms = e0.elapsed_time(e1) / reps
+        t0 = time.perf_counter()
+        _cnt, _, cf, _ = pyoracle.pool_pairs(tables, pool_ascii, threads=cores, want_dg=False, want_conflict=True)
+        dt = time.perf_counter() - t0
+        got = np.unpackbits(d_bm.cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :n]
+        out["pools"][name] = {
+            "primers": n, "checks": n * n, "ms_per_screen": ms, "checks_per_s": n * n / (ms * 1e-3),
+            "first_stage_launches_per_screen": launches / reps, "first_stage_ms": kernel_ms / max(launches, 1),
+            "handed_to_list_stages": handed / (n * n), "conflicts": int(d_rc.sum().item()),
+            "cpu_baseline": {"value": n * n / dt, "unit": "checks/s", "cores": cores, "kind": "port",
+                             "sample": f"the whole pool, {n * n} checks, {dt:.2f} s, OpenMP over rows",
+                             "decisions_equal_gpu": bool(np.array_equal(got.astype(bool), cf.astype(bool)))}}
+        del d_pool, d_rc, d_bm
+    stats = ROOT / "profiles" / "r04_small_pool_kernel_stats.csv"
+    if stats.exists():
+        out["kernel_launches"] = f"profiles/{stats.name} (rocprofv3 --kernel-trace --stats of tools/perf_small_pool.py 2000)"
+    return out
 
 
 def stage_b_line(eng, device, cpu_seconds: float):
@@ -331,20 +419,31 @@ def main():
         torch.cuda.synchronize()
 
     steps, warmup = args.steps, args.warmup
+    t_start = time.perf_counter()
     if strong:
-        # One step of the 1,048,576 pool is 1.1e12 checks (minutes): the requested counts are cut to what fits
-        # --max-seconds, from one fenced step that also serves as the first warm-up step.  Every rank takes the
-        # slowest rank's estimate, so all of them run the same number of steps.
+        # One step of the 1,048,576 pool is 1.1e12 checks (minutes).  The step counts are cut so that the WHOLE run --
+        # this estimate, the warm-up, the timed region and the CPU leg -- fits --max-seconds (450 s: the driver's limit
+        # is 600 s), but never below one timed step (on one GPU a single step is about 8 minutes: no budget holds it).
+        # The estimate: 1/16 of the rank's rows against all columns, fenced (it also builds the tables and sizes the
+        # lists: the first warm-up).  Every rank takes the slowest rank's estimate, so all run the same counts.
         fence()
         t0 = time.perf_counter()
-        step()
+        d_pool0 = gather_pool(d_shard, n)
+        est_rows = max(1, shard // 16)
+        d_conf.zero_()
+        screen_row_block(eng, d_pool0, K, chem, THRESHOLD, (r0, r0 + est_rows), d_conf,
+                         d_bitmap[:est_rows] if d_bitmap is not None else None)
         fence()
-        est = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        est = torch.tensor([(time.perf_counter() - t0) * shard / est_rows * 1.03], dtype=torch.float64, device=dev)
         all_reduce(est, dist.ReduceOp.MAX)
         per_step = max(float(est.item()), 1e-3)
-        steps = max(1, min(args.steps, int(args.max_seconds / per_step)))
-        warmup = max(0, min(args.warmup - 1, int(0.25 * args.max_seconds / per_step)))
-        warmup_done = 1
+        left = args.max_seconds - (time.perf_counter() - t_start) - (0.0 if args.no_cpu_baseline else args.cpu_seconds + 5.0)
+        steps = max(1, min(args.steps, int(left / per_step)))
+        warmup = max(0, min(args.warmup, int((left - steps * per_step) / per_step)))
+        warmup_done = 0
+        del d_pool0
+        eng.last_overflow_pairs()      # the estimate's hand-overs and stage counters are not the steps'
+        eng.pair_stage_stats()
     else:
         warmup_done = 0
     for _ in range(warmup):
@@ -389,11 +488,17 @@ def main():
         # algorithmic HBM bytes of one launch: packed operands in, conflict bitmap + counts out
         bytes_per_launch = 8.0 * (rows_per_launch + n) + per_launch_checks / 8.0 + 4.0 * rows_per_launch
         kernel_checks_per_s = per_launch_checks / max(per_launch_s, 1e-12)
+        # HBM traffic from the PMC passes (profiles/traffic_latest.json: FETCH_SIZE / WRITE_SIZE of the same kernel on
+        # this bench's pool, per check) scaled to THIS run's launch, so that it sits beside checks_per_launch /
+        # avg_launch_ms / algorithmic_bytes in the same unit: bytes per launch
         traffic = None
+        traffic_per_check = None
         tf = ROOT / "profiles" / "traffic_latest.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+                tj0 = json.loads(tf.read_text())
+                traffic_per_check = float(tj0["hbm_bytes_per_launch"]) / float(tj0["checks_per_launch"])
+                traffic = traffic_per_check * per_launch_checks
             except Exception:
                 traffic = None
         # counters come from a separate rocprofv3 --pmc run (profiles/): they are IMPORTED, not measured
@@ -427,6 +532,9 @@ def main():
             "unit": "TFLOP/s",
             "frac": kernel_checks_per_s * F64_OPS_PER_CHECK / 1e12 / FP64_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch of checks_per_launch checks (imported PMC bytes per check x this run's launch)",
+            "traffic_bytes_per_check": traffic_per_check,
+            "algorithmic_bytes": bytes_per_launch,
             "traffic_source": traffic_src,
             "f64_ops_per_check": F64_OPS_PER_CHECK,
             "launches": launches,
@@ -448,8 +556,12 @@ def main():
             cpu = cpu_baseline(pool_ascii, args.cpu_seconds,
                                d_bitmap[:min(4096, shard)].cpu().numpy().view(np.uint64) if want_bitmap else None)
         stage_a = None
+        winners = None
         if args.stage_a if args.stage_a is not None else (world == 1 and not args.pool and not strong):
-            stage_a = stage_a_line(eng, dev)
+            stage_a, winners = stage_a_line(eng, dev)
+        small_pool = None
+        if args.small_pool if args.small_pool is not None else (world == 1 and not args.pool and not strong):
+            small_pool = small_pool_line(eng, dev, winners)
         stage_b = None
         if args.stage_b if args.stage_b is not None else (world == 1 and not args.pool and not strong):
             stage_b = stage_b_line(eng, dev, args.cpu_seconds)
@@ -472,11 +584,13 @@ def main():
             "cpu_baseline": cpu,
             "stage_a": stage_a,
             "stage_b": stage_b,
+            "small_pool": small_pool,
         }
+        out["timed_region_s"] = elapsed
         if strong:
             out["steps_requested"], out["warmup_requested"] = steps_requested, warmup_requested
-            out["note"] = (f"pool1m: step counts cut to the --max-seconds {args.max_seconds:.0f} budget "
-                           f"({per_step:.1f} s per step); steps / warmup are what ran")
+            out["note"] = (f"pool1m: step counts cut to the --max-seconds {args.max_seconds:.0f} budget of the whole run "
+                           f"({per_step:.1f} s per step estimated from 1/16 of the rows); steps / warmup are what ran")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()   # rank 0 is still timing the CPU baseline: the ranks leave together

@@ -23,6 +23,42 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
+def dealt_rows(n: int, world: int, rank: int):
+    """The pool rows rank `rank` screens when the POOL'S ORDER CARRIES MEANING (stage A emits its winners by falling
+    frequency, and a row's cost depends on its base composition): groups of 256 rows dealt round robin -- the rule of
+    include/msspe_hip.h msspe_group_rows, one rule for the in-process device group and for the one-process-per-GPU
+    pipeline.  (bench.py's pools are uniformly random 13-mers: any cut is a fair sample there, and contiguous blocks
+    keep the row range a single engine call -- shard_bounds.)  uint32 numpy array, ascending."""
+    from .capi import group_rows
+    return group_rows(n, world, rank)
+
+
+def screen_dealt_rows_edges(engine, d_pool: torch.Tensor, rows, k: int, chem, threshold: float, capacity: int):
+    """Conflict edges of the scattered row set `rows` (dealt_rows) against all columns of the pool: the rows are
+    appended to a copy of the pool, P' = [pool | rows], and the engine screens the contiguous block [n, n + m) x
+    [0, n) of P' (the layout csrc/group.hip uses); edge.a is mapped back through `rows`.  Returns (edges as a list
+    of (a, b), count) -- count > capacity means the list was truncated (call again with more room)."""
+    import numpy as np
+    n, m = d_pool.numel(), int(len(rows))
+    if m == 0:
+        return [], 0
+    dev = d_pool.device
+    idx = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    d_ext = torch.cat([d_pool, d_pool[idx]])
+    d_edges = torch.zeros(capacity * 2, dtype=torch.int64, device=dev)       # 16-byte records
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    engine.cross_dimer_edges_dev(d_ext.data_ptr(), n + m, k, chem, threshold, (n, n + m), (0, n), d_edges.data_ptr(),
+                                 capacity, d_count.data_ptr())
+    torch.cuda.synchronize()
+    engine.reset_stream()
+    count = int(d_count.item())
+    if count > capacity:
+        return [], count
+    rec = d_edges[: 2 * count].cpu().numpy().view(np.dtype([("a", np.uint32), ("b", np.uint32), ("dg", np.float64)]))
+    return [(int(rows[int(e["a"]) - n]), int(e["b"])) for e in rec], count
+
+
 def _staged(t: torch.Tensor) -> bool:
     """gloo has no device collectives here: stage device tensors through the host."""
     return t.is_cuda and dist.get_backend() == "gloo"

@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 from . import capi
-from .distributed import all_reduce, shard_bounds
+from .distributed import all_reduce, dealt_rows, screen_dealt_rows_edges, shard_bounds
 
 PKG = Path(__file__).resolve().parent.parent
 
@@ -200,25 +200,18 @@ def main(argv=None) -> int:
     edges_txt = []
     if a.check_cross_dimers == "true" and nodes:
         n = len(nodes)
-        r0, r1 = shard_bounds(n, world, rank)
+        # the candidates arrive ordered by frequency, direction by direction: rows are dealt out in groups of 256, round
+        # robin (distributed.dealt_rows = msspe_group_rows), not cut into contiguous blocks
+        rows = dealt_rows(n, world, rank)
         chem = capi.Chem(_two(a.mv_conc), _two(a.dv_conc), _two(a.dntp_conc), _two(a.dna_conc), _two(a.annealing_temp), 30)
         d_pool = torch.from_numpy(capi.pack_oligos(nodes).view(np.int64)).to(dev)
-        cap = max(4096, (r1 - r0) * n // 16)
+        cap = max(4096, len(rows) * n // 16)
         mine = []
-        while r1 > r0:
-            d_edges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)       # 16-byte records
-            d_count = torch.zeros(1, dtype=torch.int64, device=dev)
-            eng.set_stream(torch.cuda.current_stream().cuda_stream)
-            eng.cross_dimer_edges_dev(d_pool.data_ptr(), n, k, chem, float(np.float32(a.delta_g_threshold)), (r0, r1), (0, n),
-                                      d_edges.data_ptr(), cap, d_count.data_ptr())
-            torch.cuda.synchronize()
-            eng.reset_stream()
-            count = int(d_count.item())
+        while len(rows):
+            mine, count = screen_dealt_rows_edges(eng, d_pool, rows, k, chem, float(np.float32(a.delta_g_threshold)), cap)
             if count > cap:
                 cap = count
                 continue
-            rec = d_edges[: 2 * count].cpu().numpy().view(np.dtype([("a", np.uint32), ("b", np.uint32), ("dg", np.float64)]))
-            mine = [(int(e["a"]), int(e["b"])) for e in rec]
             break
         gathered = [mine]
         if world > 1:
@@ -231,12 +224,12 @@ def main(argv=None) -> int:
                 if s not in rc_cache:
                     rc_cache[s] = s[::-1].translate(str.maketrans("ACGTU", "TGCAA"))
                 return rc_cache[s]
-            for part in gathered:
-                for ia, ib in sorted(part):
-                    x, y = nodes[ia], nodes[ib]
-                    if a.check_self_dimers != "true" and (x == y or revcomp(y) == x):   # delta_g.rs:66-69
-                        continue
-                    edges_txt.append(f"{x},{y}")
+            # by (a, b), as the reference's nested loops emit the pairs (delta_g.rs:64-78), whoever screened the row
+            for ia, ib in sorted(e for part in gathered for e in part):
+                x, y = nodes[ia], nodes[ib]
+                if a.check_self_dimers != "true" and (x == y or revcomp(y) == x):   # delta_g.rs:66-69
+                    continue
+                edges_txt.append(f"{x},{y}")
 
     rc = 0
     if rank == 0:

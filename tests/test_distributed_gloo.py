@@ -66,3 +66,51 @@ def test_world_size_2_matches_single_process(tmp_path, oracle, oracle_tables):
         np.testing.assert_array_equal(np.load(tmp_path / f"counts_{r}.npy"), cf.sum(1))
     rows = np.concatenate([np.load(tmp_path / f"bitmap_{r}.npy") for r in range(world)])
     np.testing.assert_array_equal(rows, cf)
+
+
+def _worker_dealt(rank: int, world: int, port: int, n: int, out_dir: str):
+    for p in (ROOT / "open-msspe-design_amd", ROOT / "oracle"):
+        sys.path.insert(0, str(p))
+    import msspe_amd
+    import pyoracle
+    from msspe_amd.distributed import dealt_rows
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pool = msspe_amd.synth.pool_strings(msspe_amd.synth.random_pool(n, 13, seed=37))
+        rows = dealt_rows(n, world, rank)
+        tables = pyoracle.Tables()
+        mine = []
+        # the oracle as the stand-in compute, one call per run of consecutive rows (groups of 256)
+        start = 0
+        while start < len(rows):
+            end = start
+            while end + 1 < len(rows) and rows[end + 1] == rows[end] + 1:
+                end += 1
+            r0, r1 = int(rows[start]), int(rows[end]) + 1
+            _, _, cf, _ = pyoracle.pool_pairs(tables, pool, rows=(r0, r1), threads=2, want_dg=False)
+            mine += [(r0 + int(i), int(j)) for i, j in zip(*np.nonzero(cf))]
+            start = end + 1
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if rank == 0:
+            edges = sorted(e for part in gathered for e in part)
+            np.save(os.path.join(out_dir, "edges.npy"), np.array(edges, dtype=np.int64).reshape(-1, 2))
+            np.save(os.path.join(out_dir, "sizes.npy"), np.array([len(p) for p in gathered]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dealt_rows_world_size_2_matches_single_process(tmp_path, oracle, oracle_tables):
+    """The pipeline's row dealing (groups of 256, round robin: distributed.dealt_rows = msspe_group_rows): two ranks'
+    edge lists, gathered and sorted by (a, b), are the single-process edge list."""
+    import msspe_amd
+    n, world, port = 600, 2, 30500 + os.getpid() % 1000      # rank 0: rows 0..255 and 512..599, rank 1: 256..511
+    mp.start_processes(_worker_dealt, args=(world, port, n, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    pool = msspe_amd.synth.pool_strings(msspe_amd.synth.random_pool(n, 13, seed=37))
+    _, _, cf, _ = oracle.pool_pairs(oracle_tables, pool, want_dg=False)
+    want = np.array(sorted((int(i), int(j)) for i, j in zip(*np.nonzero(cf))), dtype=np.int64).reshape(-1, 2)
+    np.testing.assert_array_equal(np.load(tmp_path / "edges.npy"), want)
+    assert len(want) > 100 and np.load(tmp_path / "sizes.npy").min() > 0

@@ -131,3 +131,53 @@ def test_cli_with_devices_writes_the_single_device_csv(m, tmp_path):
     arr = (C.c_char_p * len(bad))(*[a.encode() for a in bad])
     buf = C.create_string_buffer(1 << 16)
     assert host.odm_run_cli(len(bad), arr, buf, 1 << 16) == 2
+
+
+@pytest.mark.parametrize("transport", ["rccl", "device-copy", None])
+def test_group_on_two_distinct_devices_equals_one_context(m, eng, transport):
+    """Distinct devices: grouped ncclAllGather / ncclAllReduce on N communicators from one thread, peer access and
+    cross-device copies, the summing kernel on the root -- what one card cannot execute.  Skipped on a one-GPU box
+    (every box the build has had so far: these paths are NOT YET VERIFIED ON HARDWARE)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one node")
+    n = 3000
+    pool = m.synth.pool_strings(m.synth.random_pool(n, 13, seed=4321))
+    chem = m.Chem.ntthal()
+    want = eng.cross_dimer(pool, chem, -8500.0, want_dg=False)
+    want_edges, want_count = eng.cross_dimer_edges(pool, chem, -8500.0)
+    g = m.Group([0, 1], transport=transport)
+    try:
+        assert g.size == 2 and g.transport == (transport or "rccl"), (g.transport, g.transport_reason)
+        got = g.cross_dimer(pool, chem, -8500.0)
+        np.testing.assert_array_equal(got["row_conflicts"], want["row_conflicts"])
+        np.testing.assert_array_equal(got["bitmap"], want["bitmap"])
+        edges, count = g.cross_dimer_edges(pool, chem, -8500.0)
+        assert count == want_count
+        np.testing.assert_array_equal(edges, want_edges)
+        # a pool with fewer rows than members x 256: the second member screens nothing and must still be in step
+        small = pool[:200]
+        np.testing.assert_array_equal(g.cross_dimer(small, chem, -8500.0)["row_conflicts"],
+                                      eng.cross_dimer(small, chem, -8500.0, want_dg=False)["row_conflicts"])
+        e2, c2 = g.cross_dimer_edges(small, chem, -8500.0)
+        w2, wc2 = eng.cross_dimer_edges(small, chem, -8500.0)
+        assert c2 == wc2
+        np.testing.assert_array_equal(e2, w2)
+        stats = g.oligo_stats(pool[:500])
+        ref = eng.oligo_stats(pool[:500])
+        for key in ref:
+            np.testing.assert_array_equal(stats[key], ref[key])
+    finally:
+        g.close()
+
+
+def test_auto_transport_reports_why_it_runs_the_copies(m):
+    """Members that share a card cannot use RCCL: "auto" takes the copies without a reason to report (RCCL was never
+    wanted), an explicit "rccl" is refused."""
+    g = m.Group([0, 0])
+    try:
+        assert g.transport == "device-copy" and g.transport_reason == ""
+    finally:
+        g.close()
+    with pytest.raises(m.MsspeError):
+        m.Group([0, 0], transport="rccl")
