@@ -411,10 +411,7 @@ __global__ void __launch_bounds__(256) k_max_count(const int32_t *count, int M, 
             if (kRebuild) {
                 // head of a batch of the candidate-list loop: counts only fall, so until the maximum drops
                 // below theta the winner and everything tied with it are among the words collected now
-#ifndef THETA_DIV
-#define THETA_DIV 2
-#endif
-                st->theta = max(2, mf / THETA_DIV);
+                st->theta = max(2, mf / 2);
                 st->n_cand = 0;
                 st->n_mcand = 0;
                 st->epoch += 1;
@@ -1002,12 +999,6 @@ struct WalkWord {
     unsigned long long key;   // count << 32 | score bits, as of now
 };
 
-#ifdef FAST_CLOCK
-__device__ unsigned long long g_fast_clock[16];
-#define FCLK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_fast_clock[i], t_ - t_prev); t_prev = t_; } } while (0)
-#else
-#define FCLK(i) do { } while (0)
-#endif
 __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const int32_t *count, const uint32_t *cand,
                                                const uint16_t *word_part, const uint8_t *word_multi,
                                                const MultiInfo *multi, const int32_t *live_part, uint32_t *coverage,
@@ -1044,9 +1035,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     __shared__ unsigned ws_chunks;
     __shared__ uint32_t ws_last;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#ifdef FAST_CLOCK
-    unsigned long long t_prev = wall_clock64();
-#endif
     // (single block, and the only writer of the loop's flags besides k_prefix, which does not run when this did)
     const int stop = st->stop, rebuild_state = st->need_rebuild;
     const unsigned n_cand = st->n_cand, n_mcand = st->n_mcand;
@@ -1091,7 +1079,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         }
         return;
     }
-    FCLK(0);
     for (int e = tid; e < P; e += 1024) {
         lead[e] = 0ull;
         lp_s[e] = live_part[e];
@@ -1129,7 +1116,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = max(m, red[w]);
-    FCLK(1);
     if (m < theta) {   // a word outside the list may be ahead now
         if (tid == 0) st->need_rebuild = 1;
         return;
@@ -1138,7 +1124,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     // have more than the runner-up has now -- counts only fall -- however many live segments the partition keeps: the
     // bound that still works late in the loop, when a leader covers a small part of what its partition has left)
     __syncthreads();
-    FCLK(2);
     // the entries: leaders with a count of at least theta (nothing below it may be accepted from this list) ...
     for (int p0 = 0; p0 < P; p0 += 1024) {
         const int p = p0 + tid;
@@ -1200,7 +1185,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     }
     const int n_ent = n_ent_sh;
     __syncthreads();
-    FCLK(3);
     // rank by counting; equal (count, score): the smaller word first.  1024 / n_ent threads share an entry.
     for (int i = tid; i < n_ent; i += 1024) rank_s[i] = 0;
     __syncthreads();
@@ -1222,7 +1206,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
     for (int i = tid; i < n_ent; i += 1024)
         if (rank_s[i] < kFastTop) top[rank_s[i]] = i;
     __syncthreads();
-    FCLK(4);
     {
         // The walk below is one thread's, and every global load in it would be a dependent one (about 200 ns each, six per
         // winner when it read them itself): all the threads fetch what it will read -- the entries' words and posting-list
@@ -1255,7 +1238,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         if (sink == 0x9e3779b9u) red[0] = (int)sink;   // (keeps the loads)
     }
     __syncthreads();
-    FCLK(5);
     const int min_freq = st->min_freq;
     const uint32_t it_now = (uint32_t)(st->it_fast + st->it_general + 1);
     const int limit = min(n_ent, kFastTop);
@@ -1404,11 +1386,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
                 const int f = (int)(w.key >> 32), ent = w.ent, wj = w.j;
                 const uint32_t kid = lkid[ent];
                 const MultiInfo *mi = wj >= 0 ? (mi_slot[wj] != 0xff ? &mi_s[mi_slot[wj]] : &multi[wj]) : nullptr;
-    #ifdef FAST_CLOCK
-                atomicAdd(&g_fast_clock[8], 1ull);
-                if (mi) atomicAdd(&g_fast_clock[9], 1ull);
-                if (from_pend) atomicAdd(&g_fast_clock[10], 1ull);
-    #endif
                 if (!mi) {   // a partition's leader
                     const int p = lwho[ent];
                     if (ub[p] >= 0) {   // its partition was touched: it is passed over, with what it can still have
@@ -1567,7 +1544,6 @@ __global__ void __launch_bounds__(1024) k_fast(Status *st, PickState *ps, const 
         n_bump = nb;
     }
     __syncthreads();
-    FCLK(6);
     if (tid < n_bump) atomicAdd(&coverage[bump[tid]], 1u);   // main.rs:371-378: once per partition of a winner's posting list
 }
 
@@ -2114,12 +2090,6 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
     constexpr unsigned kSpan = 16;   // chunks per work item: one per wave
     __shared__ int32_t tkey[kCoverTbl], tval[kCoverTbl];
     __shared__ uint32_t cum_s[kMaxPick + 1], kid_s[kMaxPick], span_s[kMaxPick + 1];
-#ifdef FAST_CLOCK
-    unsigned long long t_prev = wall_clock64();
-#define CCLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (i == 11 || span_s[np < 64 ? np : 64] <= 32u)) { if (i == 15) atomicAdd(&g_fast_clock[7], 1ull); const unsigned long long t_ = wall_clock64(); atomicAdd(&g_fast_clock[i], t_ - t_prev); t_prev = t_; } } while (0)
-#else
-#define CCLK(i) do { } while (0)
-#endif
     const unsigned np = ps->n_pick;
     if (np == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2140,7 +2110,6 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
     }
     __syncthreads();
     const unsigned total = span_s[np < 64 ? np : 64];
-    CCLK(11);
     if (blockIdx.x >= total) return;   // block-uniform: most blocks of a late iteration
     for (int e = tid; e < kCoverTbl; e += 1024) {
         tkey[e] = -1;
@@ -2174,13 +2143,10 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
                 const unsigned old = atomicOr(reinterpret_cast<unsigned *>(ignored + (row & ~3u)), 1u << sh8);
                 live = ((old >> sh8) & 0xffu) == 0u;
             }
-            CCLK(12);
             take_live(live_part, live && mk, part, lane);
             if (__ballot(live)) cover_wave_table(row, live, per, G, kid_of_inst, count, tkey, tval, total >= kCoverHeavy);
         }
-        CCLK(13);
         __syncthreads();
-        CCLK(14);
         for (int e = tid; e < kCoverTbl; e += 1024) {   // the table goes to memory and is empty again
             const int32_t k = tkey[e];
             if (k >= 0) {
@@ -2190,7 +2156,6 @@ __global__ void __launch_bounds__(1024) k_cover_multi(const PickState *ps, const
             }
         }
         __syncthreads();
-        CCLK(15);
     }
 }
 
@@ -2534,10 +2499,7 @@ int KmerStage::run(const SeqView &d_seqs, int n_seq, size_t seq_len, const msspe
     };
     // a batch of kBatch iterations is ONE graph (fewer graph launches than one graph per iteration)
     constexpr int kBatch = 32;
-#ifndef MSSPE_BATCHN
-#define MSSPE_BATCHN 8
-#endif
-    constexpr int kBatchN = MSSPE_BATCHN;    // candidate-list iterations per graph (an iteration selects up to 64 winners)
+    constexpr int kBatchN = 8;    // candidate-list iterations per graph (an iteration selects up to 64 winners)
     GraphGuard gg[2];   // 0: five-launch iterations, 1: candidate-list iterations
     bool use_graph = use_graph_;   // option "stage_a_graph" (0: plain launches, a testing aid)
     auto capture = [&](int which) -> bool {
@@ -2691,9 +2653,3 @@ int KmerStage::coverage(const SeqView &d_seqs, int n_seq, size_t seq_len, const 
 
 }  // namespace msspe
 
-#ifdef FAST_CLOCK
-extern "C" int msspe_debug_fast_clock(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(msspe::g_fast_clock), sizeof(msspe::g_fast_clock));
-}
-#endif

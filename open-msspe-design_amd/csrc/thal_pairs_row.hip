@@ -39,6 +39,7 @@
 // Ties, maxTM, the terminal pick, the traceback by pointer and the f64 replay of the optimal path are
 // those of thal_pairs_int.hip; a pair this kernel does not answer goes to the same hand-over list.
 #include "int_core.hpp"
+#include "row_scan_pinned.inc"
 
 
 namespace msspe {
@@ -51,6 +52,10 @@ namespace {
 template <int ROWK, int ROWT, int ROWS, bool ROWOOB>
 struct RowKernel {
 static constexpr int kRowK = ROWK;                      // longest oligo of this instance
+// The 13-base instance binds its slot table to FIXED registers: its scan and its publish are inline asm whose tuple
+// operands carry explicit register ranges, the scan one generated block (tools/gen_row_scan_asm.py ->
+// row_scan_pinned.inc: register map and reasons there).  The other instances leave the tuples to the allocator.
+static constexpr bool kPin = ROWK == 13 && ROWT == 768 && ROWS == 52 && ROWOOB;
 static constexpr int kRowThreads = ROWT, kRowSlots = ROWS;   // 13 bases: 768 threads (three waves per SIMD), 52 stored cells per pair
 static constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. k - 2
 static constexpr int kRowR = kRowK + 1;                 // digits of the row index: 14 i + (i - ii) at 13 bases
@@ -282,6 +287,38 @@ static __device__ __forceinline__ void scan_fill_row(MSSPE_TAB_PARAMS, unsigned 
     }
 }
 
+// ---- the 13-base instance's scan and publish over the register-bound table (kPin) -------------------------------------
+struct PinScan {
+    int bestG, bestW, G2, stkG, stkW;
+    unsigned long long stHave;
+};
+static __device__ __forceinline__ PinScan pin_scan(const v32i Ga, const v32i Wa, const v16i Gb, const v16i Wb, const v4i Gc,
+                                            const v4i Wc, const RCell &c, unsigned run, unsigned far, int near_from)
+{
+    PinScan r;
+    int a0, a1, a2, a3, t0, t1, t2, t3;
+    asm volatile(MSSPE_ROW13_SCAN_ASM
+                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), [BG] "=&v"(r.bestG), [BW] "=&v"(r.bestW),
+                   [B2] "=&v"(r.G2), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
+                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [RUN] "s"(run), [FAR] "s"(far), [NEAR] "s"(near_from),
+                   [TOFF] "n"((int)offsetof(SharedRow, T)), [INIT] "n"(kRowInit), MSSPE_ROW13_TUPLES_IN(Ga, Gb, Gc, Wa, Wb, Wc)
+                 : MSSPE_ROW13_SCAN_CLOBBERS);
+    return r;
+}
+// slot: wave-uniform, < kRowSlots.  One indexed write per plane, whatever tuple the slot falls into.
+static __device__ __forceinline__ void pin_publish(v32i &Ga, v32i &Wa, v16i &Gb, v16i &Wb, v4i &Gc, v4i &Wc, int slot, int G0s,
+                                            int Wcell)
+{
+    asm volatile("s_set_gpr_idx_on %[SLOT], gpr_idx(DST)\n\t"
+                 "v_mov_b32 v%c[G0], %[G]\n\t"
+                 "v_mov_b32 v%c[W0], %[W]\n\t"
+                 "s_set_gpr_idx_off"
+                 : MSSPE_ROW13_TUPLES_INOUT(Ga, Gb, Gc, Wa, Wb, Wc)
+                 : [G] "v"(G0s), [W] "v"(Wcell), [SLOT] "s"(slot), [G0] "n"(MSSPE_ROW13_G0), [W0] "n"(MSSPE_ROW13_W0)
+                 : "m0");
+}
+
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  !active: idle lane.  n_slots: the slots the
 // wave's rows take (all rows but the last, padded to the widest lane); wmax4: the widest lane's count of each base.
 template <int NS>
@@ -343,7 +380,14 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         sm.tie = sm.stHave = 0ull;
         // predecessors: every slot of the rows above; row i-1 (where the cell (i-1, j-1) lives) through
         // the code that catches it
-        {
+        if constexpr (kPin) {
+            const PinScan ps = pin_scan(Ga, Wa, Gb, Wb, Gc, Wc, rc, run_chunks, far_chunks, start_im1);
+            rb.GW = __hiloint2double(ps.bestG, ps.bestW);
+            rb.G2 = ps.G2;
+            stk.G = ps.stkG;
+            stk.W = ps.stkW;
+            sm.stHave = ps.stHave;
+        } else {
             unsigned run = run_chunks, far = far_chunks;
             asm volatile("" : "+s"(run), "+s"(far));   // the per-chunk bit tests stay where they are used
             scan_fill_row<NS>(MSSPE_TAB_ARGS, run, far, start_im1, (const char *)sh.T, rc, rb, stk, sm);
@@ -424,6 +468,9 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         // ---- publish the cell (idle lanes write a slot nobody reads)
         // (the cells of the last row all take the first free slot number -- or 52, which is written nowhere --:
         //  nothing reads it, no row follows and the walk back only matches predecessors)
+        if constexpr (kPin) {
+            if (slot < NS) pin_publish(Ga, Wa, Gb, Wb, Gc, Wc, slot, G0s, Wcell);   // (slot 52: cells of the last row of a full table, written nowhere)
+        } else
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0s;
             Wa[slot & 31] = Wcell;

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates open-msspe-design_amd/csrc/row_scan_pinned.inc: the predecessor scan of thal_pairs_row.hip's 13-base
+instance as ONE inline-asm block over a slot table that lives in hand-assigned registers.
+
+Why: the table (52 slots x {value G, word W} = 104 VGPRs) is read with compile-time register numbers and written
+through a wave-uniform index.  As compiler-managed register tuples (v32i + v16i + v4i per plane) every cell paid
+register copies the allocator could not coalesce: two per skipped chunk on the way out of the scan's nested exits, and
+about 45 64-bit copies around the indexed write of every slot from 32 up.  The VALU of this kernel is 93 % busy at a
+flat 4 cycles per instruction (profiles/r03_pmc_k_pairs_row.txt: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles), so
+instructions are time.  Here the tuples are bound to FIXED registers wherever they are touched -- the scan and the
+publish are inline asm whose tuple operands carry explicit register ranges ("{v[62:93]}" ...), so the allocator keeps
+them there for good and everything else of the kernel around them -- and the scan is what it is on paper -- far
+visit: sub, lshr, [ds_read], add3, mov, med3, min_f64 -- with one exit and no copies; the publish is two moves for
+any slot (GPR-index mode over the whole 52-register plane, tuple boundaries or not).
+
+Register map (168 VGPRs = three waves per SIMD):
+    v57           G2: runner-up of the running minimum            (scan-internal: clobbered, free outside the scan)
+    v58:59, v60:61  operand pairs (value : word) of v_min_f64     (scan-internal)
+    v62 .. v113   G[0 .. 51]   slot values (+ kRowZero)           = Ga v[62:93], Gb v[94:109], Gc v[110:113]
+    v114 .. v165  W[0 .. 51]   slot words                         = Wa v[114:145], Wb v[146:161], Wc v[162:165]
+    v166:167      running minimum (value : word)                  (scan-internal)
+    everything else: the compiler's
+usage: tools/gen_row_scan_asm.py > open-msspe-design_amd/csrc/row_scan_pinned.inc
+"""
+NS, KC = 52, 4
+G2 = 57
+PAIR = (58, 60)
+G0, W0 = 62, 114
+ACC = 166
+
+
+def scan_asm():
+    L = []
+    a = lambda s: L.append(s)
+    # operands: %[C] %[Y] v; %[IDX] %[RUN] %[FAR] %[NEAR] s; outputs %[SG] %[SW] v, %[HV] s64, %[BG] %[BW] %[B2] v;
+    # temps %[a0..a3] %[t0..t3] %[BG] v, m0 s; immediates %[TOFF] %[INIT]
+    a(f"v_mov_b32 v{ACC + 1}, %[INIT]")
+    a(f"v_mov_b32 v{ACC}, 0")
+    a(f"v_bfrev_b32 v{G2}, -2")               # 0x7fffffff
+    a("v_mov_b32 %[SG], 0")
+    a("v_mov_b32 %[SW], 0")
+    a("s_mov_b64 %[HV], 0")
+    nch = NS // KC
+    for pc in range(nch):
+        g = [G0 + pc * KC + e for e in range(KC)]
+        w = [W0 + pc * KC + e for e in range(KC)]
+        a(f"s_bitcmp0_b32 %[RUN], {pc}")
+        a("s_cbranch_scc1 Ldone%=")
+        for e in range(KC):
+            a(f"v_sub_u32 %[a{e}], %[C], v{w[e]}")
+        for e in range(KC):
+            a(f"v_lshrrev_b32 %[a{e}], 15, %[a{e}]")
+        for e in range(KC):
+            a(f"ds_read_b32 %[t{e}], %[a{e}] offset:%c[TOFF]")
+        a(f"s_bitcmp0_b32 %[FAR], {pc}")
+        a(f"s_cbranch_scc1 Lnf{pc}_%=")
+        # ---- far: rows i-2 and above, every entry takes the cell-side term
+        def tail(e):   # runner-up and minimum of visit e (its operand pair is ready)
+            p = PAIR[e & 1]
+            a(f"v_med3_i32 v{G2}, v{ACC + 1}, v{G2}, v{p + 1}")
+            a(f"v_min_f64 v[{ACC}:{ACC + 1}], v[{ACC}:{ACC + 1}], v[{p}:{p + 1}]")
+        for e in range(KC):
+            p = PAIR[e & 1]
+            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
+            a(f"v_add3_u32 v{p + 1}, %[t{e}], %[Y], v{g[e]}")
+            a(f"v_mov_b32 v{p}, v{w[e]}")
+            if e >= 1:
+                tail(e - 1)
+        tail(KC - 1)
+        a(f"s_branch Lnx{pc}_%=")
+        a(f"Lnf{pc}_%=:")
+        a(f"s_sub_i32 m0, %[NEAR], {pc * KC}")
+        a("s_cmp_lt_i32 m0, 1")
+        a(f"s_cbranch_scc1 Lnr{pc}_%=")
+        # ---- straddle: the first rem slots still belong to row i-2 (cell-side term), the rest to row i-1
+        def stk(e):
+            a(f"v_cmp_eq_u32_e32 vcc, %[IDX], %[a{e}]")
+            a(f"v_cndmask_b32_e32 %[SG], %[SG], v{g[e]}, vcc")
+            a(f"v_cndmask_b32_e32 %[SW], %[SW], v{w[e]}, vcc")
+            a("s_or_b64 %[HV], %[HV], vcc")
+        for e in range(KC):
+            p = PAIR[e & 1]
+            a(f"s_cmp_gt_i32 m0, {e}")
+            a("s_cselect_b64 vcc, -1, 0")
+            a("v_cndmask_b32_e32 %[BG], 0, %[Y], vcc")
+            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
+            a(f"v_add3_u32 v{p + 1}, %[t{e}], %[BG], v{g[e]}")
+            a(f"v_mov_b32 v{p}, v{w[e]}")
+            if e >= 1:
+                tail(e - 1)
+            stk(e)
+        tail(KC - 1)
+        a(f"s_branch Lnx{pc}_%=")
+        a(f"Lnr{pc}_%=:")
+        # ---- near: the row above the cell only -- no cell-side term; the cell (i-1, j-1) is among these
+        for e in range(KC):
+            p = PAIR[e & 1]
+            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
+            a(f"v_add_u32 v{p + 1}, %[t{e}], v{g[e]}")
+            a(f"v_mov_b32 v{p}, v{w[e]}")
+            if e >= 1:
+                tail(e - 1)
+            stk(e)
+        tail(KC - 1)
+        a(f"Lnx{pc}_%=:")
+    a("Ldone%=:")
+    a(f"v_mov_b32 %[BG], v{ACC + 1}")
+    a(f"v_mov_b32 %[BW], v{ACC}")
+    a(f"v_mov_b32 %[B2], v{G2}")
+    return L
+
+
+def clobbers():
+    regs = [G2] + [PAIR[0], PAIR[0] + 1, PAIR[1], PAIR[1] + 1] + [ACC, ACC + 1]
+    return regs
+
+
+def cstr(lines):
+    return "\n".join('    "' + l + '\\n\\t"' for l in lines)
+
+
+print("// GENERATED by tools/gen_row_scan_asm.py -- do not edit (see that file for the why and the register map)")
+print(f"#define MSSPE_ROW13_G0 {G0}")
+print(f"#define MSSPE_ROW13_W0 {W0}")
+print("#define MSSPE_ROW13_SCAN_ASM \\")
+print(" \\\n".join('    "' + l + '\\n\\t"' for l in scan_asm()))
+print("#define MSSPE_ROW13_SCAN_CLOBBERS " + ", ".join(f'"v{r}"' for r in clobbers()) + ', "vcc", "scc", "m0", "memory"')
+print('#define MSSPE_ROW13_TUPLES_IN(Ga, Gb, Gc, Wa, Wb, Wc) "{v[%d:%d]}"(Ga), "{v[%d:%d]}"(Gb), "{v[%d:%d]}"(Gc), '
+      '"{v[%d:%d]}"(Wa), "{v[%d:%d]}"(Wb), "{v[%d:%d]}"(Wc)' % (G0, G0 + 31, G0 + 32, G0 + 47, G0 + 48, G0 + 51,
+                                                                W0, W0 + 31, W0 + 32, W0 + 47, W0 + 48, W0 + 51))
+print('#define MSSPE_ROW13_TUPLES_INOUT(Ga, Gb, Gc, Wa, Wb, Wc) "+{v[%d:%d]}"(Ga), "+{v[%d:%d]}"(Gb), "+{v[%d:%d]}"(Gc), '
+      '"+{v[%d:%d]}"(Wa), "+{v[%d:%d]}"(Wb), "+{v[%d:%d]}"(Wc)' % (G0, G0 + 31, G0 + 32, G0 + 47, G0 + 48, G0 + 51,
+                                                                   W0, W0 + 31, W0 + 32, W0 + 47, W0 + 48, W0 + 51))

@@ -45,13 +45,3 @@ for direction in (0, 1):
     print("   selected as [all-words, leader, several-partition, re-keyed, walked]:", kinds, " kind of each iteration's last winner:", np.bincount(ends, minlength=5).tolist())
     print(f"dir {direction}: {len(words)} winners, top freq {freqs[:3].tolist()}, {dt*1e3:.1f} ms, "
           f"{segs/dt/1e6:.2f} M segments/s; iterations fast/general/rebuilds/idle {its}", flush=True)
-
-try:   # -DFAST_CLOCK builds only: k_fast's time per phase
-    import ctypes
-    from msspe_amd import capi as _c
-    fn = _c.load_library().msspe_debug_fast_clock
-    buf = (ctypes.c_ulonglong * 16)()
-    fn(buf)
-    print("k_fast phase clocks (10 ns ticks, all runs):", list(buf)[:16], flush=True)
-except AttributeError:
-    pass
