@@ -293,7 +293,7 @@ struct PinScan {
     unsigned long long stHave;
 };
 static __device__ __forceinline__ PinScan pin_scan(const v32i Ga, const v32i Wa, const v16i Gb, const v16i Wb, const v4i Gc,
-                                            const v4i Wc, const RCell &c, unsigned run, unsigned far, int near_from)
+                                            const v4i Wc, const RCell &c, int n_far, int n_run, int near_from)
 {
     PinScan r;
     int a0, a1, a2, a3, t0, t1, t2, t3;
@@ -301,7 +301,7 @@ static __device__ __forceinline__ PinScan pin_scan(const v32i Ga, const v32i Wa,
                  : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), [BG] "=&v"(r.bestG), [BW] "=&v"(r.bestW),
                    [B2] "=&v"(r.G2), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
                    [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-                 : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [RUN] "s"(run), [FAR] "s"(far), [NEAR] "s"(near_from),
+                 : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [NFAR] "s"(n_far), [NRUN] "s"(n_run), [NEAR] "s"(near_from),
                    [TOFF] "n"((int)offsetof(SharedRow, T)), [INIT] "n"(kRowInit), MSSPE_ROW13_TUPLES_IN(Ga, Gb, Gc, Wa, Wb, Wc)
                  : MSSPE_ROW13_SCAN_CLOBBERS);
     return r;
@@ -381,7 +381,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         // predecessors: every slot of the rows above; row i-1 (where the cell (i-1, j-1) lives) through
         // the code that catches it
         if constexpr (kPin) {
-            const PinScan ps = pin_scan(Ga, Wa, Gb, Wb, Gc, Wc, rc, run_chunks, far_chunks, start_im1);
+            const PinScan ps = pin_scan(Ga, Wa, Gb, Wb, Gc, Wc, rc, start_im1 / kC, (row_start + kC - 1) / kC, start_im1);
             rb.GW = __hiloint2double(ps.bestG, ps.bestW);
             rb.G2 = ps.G2;
             stk.G = ps.stkG;
@@ -396,7 +396,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         RBest best;
         best.G = best_g(rb) - kRowD;
         best.W = best_w(rb);
-        const bool stHave = lane_bit(sm.stHave);
+        const bool stHave = __builtin_amdgcn_inverse_ballot_w64(sm.stHave);   // the mask IS the lane predicate: no select + compare
         const CellBases b = cell_bases(q, im1, jm1, c);   // after the scan: nothing of it is live across it
         // ---- thal.c maxTM(): helix extension if it raises Tm (see thal_pairs_int.hip).  Enthalpies in units
         //      of 10 cal/mol (h): T = A / B with A = 10 (h + 20 + rh), 620300 B = 20000 h - G + cq; the
@@ -410,7 +410,8 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
             const int h1 = word_h(stk.W) + hwc;
             const int G1 = stk.G + (gwc - kRowZero);
             const double A0 = (double)(h0 + 20 + rh), A1 = (double)(h1 + 20 + rh);
-            const double B0 = (double)(20000 * h0 - G0) + cq, B1 = (double)(20000 * h1 - G1) + cq;
+            // (|h| < 2^14: a 24-bit multiply -- the 32-bit one issues at a quarter of the rate)
+            const double B0 = (double)(__mul24(20000, h0) - G0) + cq, B1 = (double)(__mul24(20000, h1) - G1) + cq;
             const double lhs = A1 * B0, rhs = A0 * B1;
             const bool sure = (B0 < 0.0) & (B1 < 0.0) & (fabs(lhs - rhs) > 1e-9 * (fabs(lhs) + fabs(rhs)));
             flags |= sure ? 0 : kDeferTm;
@@ -430,7 +431,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
             if (best.G < G0) {
                 flags |= tie ? kDeferLoopTie : 0;
                 // thal.c rejects a candidate with H > 0 and S > 0 (620300 S = 2000 H - G)
-                flags |= ((hw > 0) & (20000 * hw - best.G > -1000)) ? kDeferBad : 0;
+                flags |= ((hw > 0) & (__mul24(20000, hw) - best.G > -1000)) ? kDeferBad : 0;
                 h0 = hw;
                 G0 = best.G;
                 pred = word_cw(best.W);

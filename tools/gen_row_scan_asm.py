@@ -32,77 +32,103 @@ ACC = 166
 def scan_asm():
     L = []
     a = lambda s: L.append(s)
-    # operands: %[C] %[Y] v; %[IDX] %[RUN] %[FAR] %[NEAR] s; outputs %[SG] %[SW] v, %[HV] s64, %[BG] %[BW] %[B2] v;
-    # temps %[a0..a3] %[t0..t3] %[BG] v, m0 s; immediates %[TOFF] %[INIT]
+    # operands: %[C] %[Y] v; %[IDX] %[NFAR] %[NRUN] %[NEAR] s; outputs %[SG] %[SW] v, %[HV] s64, %[BG] %[BW] %[B2] v;
+    # temps %[a0..a3] %[t0..t3] v (two sets of four: address -> loaded value in place); immediates %[TOFF] %[INIT]
+    nch = NS // KC
+    SETS = (["%[a0]", "%[a1]", "%[a2]", "%[a3]"], ["%[t0]", "%[t1]", "%[t2]", "%[t3]"])
+    G = lambda pc, e: G0 + pc * KC + e
+    W = lambda pc, e: W0 + pc * KC + e
+
+    def tail(e):   # runner-up and minimum of visit e (its operand pair is ready)
+        p = PAIR[e & 1]
+        a(f"v_med3_i32 v{G2}, v{ACC + 1}, v{G2}, v{p + 1}")
+        a(f"v_min_f64 v[{ACC}:{ACC + 1}], v[{ACC}:{ACC + 1}], v[{p}:{p + 1}]")
+
+    def loads(pc, addr, data):
+        for e in range(KC):
+            a(f"v_sub_u32 {addr[e]}, %[C], v{W(pc, e)}")
+        for e in range(KC):
+            a(f"v_lshrrev_b32 {addr[e]}, 15, {addr[e]}")
+        for e in range(KC):
+            a(f"ds_read_b32 {data[e]}, {addr[e]} offset:%c[TOFF]")
+
+    def far_process(pc, data, newer):   # newer: loads issued after this chunk's (the next chunk's prefetch)
+        for e in range(KC):
+            p = PAIR[e & 1]
+            a(f"s_waitcnt lgkmcnt({newer + KC - 1 - e})")
+            a(f"v_add3_u32 v{p + 1}, {data[e]}, %[Y], v{G(pc, e)}")
+            a(f"v_mov_b32 v{p}, v{W(pc, e)}")
+            if e >= 1:
+                tail(e - 1)
+        tail(KC - 1)
+
     a(f"v_mov_b32 v{ACC + 1}, %[INIT]")
     a(f"v_mov_b32 v{ACC}, 0")
     a(f"v_bfrev_b32 v{G2}, -2")               # 0x7fffffff
     a("v_mov_b32 %[SG], 0")
     a("v_mov_b32 %[SW], 0")
     a("s_mov_b64 %[HV], 0")
-    nch = NS // KC
+    # ---- far chunks (slots of rows i-2 and above: every entry takes the cell-side term), software-pipelined: the next
+    #      chunk's addresses and table reads are issued before this chunk's candidates are reduced; the loaded value
+    #      lands in its address register (two sets of four, used alternately)
+    a("s_cmp_lt_i32 %[NFAR], 1")
+    a("s_cbranch_scc1 Lnear0_%=")
+    loads(0, SETS[0], SETS[0])
     for pc in range(nch):
-        g = [G0 + pc * KC + e for e in range(KC)]
-        w = [W0 + pc * KC + e for e in range(KC)]
-        a(f"s_bitcmp0_b32 %[RUN], {pc}")
-        a("s_cbranch_scc1 Ldone%=")
-        for e in range(KC):
-            a(f"v_sub_u32 %[a{e}], %[C], v{w[e]}")
-        for e in range(KC):
-            a(f"v_lshrrev_b32 %[a{e}], 15, %[a{e}]")
-        for e in range(KC):
-            a(f"ds_read_b32 %[t{e}], %[a{e}] offset:%c[TOFF]")
-        a(f"s_bitcmp0_b32 %[FAR], {pc}")
-        a(f"s_cbranch_scc1 Lnf{pc}_%=")
-        # ---- far: rows i-2 and above, every entry takes the cell-side term
-        def tail(e):   # runner-up and minimum of visit e (its operand pair is ready)
+        cur = SETS[pc & 1]
+        if pc + 1 < nch:
+            a(f"s_cmp_gt_i32 %[NFAR], {pc + 1}")
+            a(f"s_cbranch_scc0 Lfl{pc}_%=")
+            loads(pc + 1, SETS[(pc + 1) & 1], SETS[(pc + 1) & 1])
+            far_process(pc, cur, KC)
+            a(f"s_branch Lff{pc + 1}_%=")
+            a(f"Lfl{pc}_%=:")
+        far_process(pc, cur, 0)
+        if pc + 1 < nch:
+            a(f"s_branch Lnear{pc + 1}_%=")
+            a(f"Lff{pc + 1}_%=:")
+    a("s_branch Ldone%=")
+    # ---- the chunks behind the far ones: the one that straddles rows i-2 and i-1 (the first rem slots take the
+    #      cell-side term) and the ones of row i-1 alone; the cell (i-1, j-1) is among these slots
+    def stk(pc, e, addr):
+        a(f"v_cmp_eq_u32_e32 vcc, %[IDX], {addr[e]}")
+        a(f"v_cndmask_b32_e32 %[SG], %[SG], v{G(pc, e)}, vcc")
+        a(f"v_cndmask_b32_e32 %[SW], %[SW], v{W(pc, e)}, vcc")
+        a("s_or_b64 %[HV], %[HV], vcc")
+    for pc in range(nch):
+        addr, data = SETS
+        a(f"Lnear{pc}_%=:")
+        a(f"s_cmp_gt_i32 %[NRUN], {pc}")
+        a("s_cbranch_scc0 Ldone%=")
+        loads(pc, addr, data)
+        a(f"s_cmp_gt_i32 %[NEAR], {pc * KC}")
+        a(f"s_cbranch_scc0 Lnr{pc}_%=")
+        for e in range(KC):   # straddle
             p = PAIR[e & 1]
-            a(f"v_med3_i32 v{G2}, v{ACC + 1}, v{G2}, v{p + 1}")
-            a(f"v_min_f64 v[{ACC}:{ACC + 1}], v[{ACC}:{ACC + 1}], v[{p}:{p + 1}]")
-        for e in range(KC):
-            p = PAIR[e & 1]
-            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
-            a(f"v_add3_u32 v{p + 1}, %[t{e}], %[Y], v{g[e]}")
-            a(f"v_mov_b32 v{p}, v{w[e]}")
-            if e >= 1:
-                tail(e - 1)
-        tail(KC - 1)
-        a(f"s_branch Lnx{pc}_%=")
-        a(f"Lnf{pc}_%=:")
-        a(f"s_sub_i32 m0, %[NEAR], {pc * KC}")
-        a("s_cmp_lt_i32 m0, 1")
-        a(f"s_cbranch_scc1 Lnr{pc}_%=")
-        # ---- straddle: the first rem slots still belong to row i-2 (cell-side term), the rest to row i-1
-        def stk(e):
-            a(f"v_cmp_eq_u32_e32 vcc, %[IDX], %[a{e}]")
-            a(f"v_cndmask_b32_e32 %[SG], %[SG], v{g[e]}, vcc")
-            a(f"v_cndmask_b32_e32 %[SW], %[SW], v{w[e]}, vcc")
-            a("s_or_b64 %[HV], %[HV], vcc")
-        for e in range(KC):
-            p = PAIR[e & 1]
-            a(f"s_cmp_gt_i32 m0, {e}")
+            a(f"s_cmp_gt_i32 %[NEAR], {pc * KC + e}")
             a("s_cselect_b64 vcc, -1, 0")
             a("v_cndmask_b32_e32 %[BG], 0, %[Y], vcc")
             a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
-            a(f"v_add3_u32 v{p + 1}, %[t{e}], %[BG], v{g[e]}")
-            a(f"v_mov_b32 v{p}, v{w[e]}")
+            a(f"v_add3_u32 v{p + 1}, {data[e]}, %[BG], v{G(pc, e)}")
+            a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:
                 tail(e - 1)
-            stk(e)
+            stk(pc, e, addr)
         tail(KC - 1)
-        a(f"s_branch Lnx{pc}_%=")
+        if pc + 1 < nch:
+            a(f"s_branch Lnear{pc + 1}_%=")
+        else:
+            a("s_branch Ldone%=")
         a(f"Lnr{pc}_%=:")
-        # ---- near: the row above the cell only -- no cell-side term; the cell (i-1, j-1) is among these
-        for e in range(KC):
+        for e in range(KC):   # row i-1 only
             p = PAIR[e & 1]
             a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
-            a(f"v_add_u32 v{p + 1}, %[t{e}], v{g[e]}")
-            a(f"v_mov_b32 v{p}, v{w[e]}")
+            a(f"v_add_u32 v{p + 1}, {data[e]}, v{G(pc, e)}")
+            a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:
                 tail(e - 1)
-            stk(e)
+            stk(pc, e, addr)
         tail(KC - 1)
-        a(f"Lnx{pc}_%=:")
     a("Ldone%=:")
     a(f"v_mov_b32 %[BG], v{ACC + 1}")
     a(f"v_mov_b32 %[BW], v{ACC}")
