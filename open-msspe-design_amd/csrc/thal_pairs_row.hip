@@ -335,7 +335,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
     c.rH = 0;
     c.im1p = c.jm1p = 0;
     c.yTS = c.yMM = c.bBase = 0;
-    sh.pick[0][threadIdx.x] = 0x7fffffff;   // pickG
+    int pick_g = 0x7fffffff;                // the terminal pick's value so far (a register: it is read by every cell)
     sh.pick[1][threadIdx.x] = 0;            // pickW
     sh.pick[2][threadIdx.x] = 0;            // nTie
     sh.pick[3][threadIdx.x] = 0xff;
@@ -405,7 +405,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         int h0 = sh.h[b.idxL - kRowGBase], G0 = sh.g[b.idxL - kRowGBase], pred = 0xff, flags = 0, cell_soft = 0;
         const int rh = sh.h[b.idxR - kRowGBase], gR = sh.g[b.idxR - kRowGBase], hwc = sh.h[b.wc - kRowGBase], gwc = sh.g[b.wc - kRowGBase];
         const double cq = sh.cq[b.idxR - FastTables::kEndR];
-        const int pickG = sh.pick[0][threadIdx.x];
+        const int pickG = pick_g;
         if (stHave) {
             const int h1 = word_h(stk.W) + hwc;
             const int G1 = stk.G + (gwc - kRowZero);
@@ -455,7 +455,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         {
             const int Gt = G0 + gR;
             if (in & (Gt < pickG)) {
-                sh.pick[0][threadIdx.x] = Gt;
+                pick_g = Gt;
                 sh.pick[1][threadIdx.x] = Wcell;
                 sh.pick[2][threadIdx.x] = 0;
                 sh.pick[3][threadIdx.x] = pred | cell_soft;

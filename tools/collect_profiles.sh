@@ -22,5 +22,7 @@ echo "stage a done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_b_stats -o stageb -- python3 tools/perf_stage_b.py 1048576 > $OUT/stage_b_stdout.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stage_b2k_stats -o stageb2k -- python3 tools/perf_stage_b.py 2000 > $OUT/stage_b2k_stdout.log 2>&1 || exit 1
 echo "stage b done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small_pool_stats -o smallpool -- python3 tools/perf_small_pool.py 2000 --reps 20 > $OUT/small_pool_stdout.log 2>&1 || exit 1
+echo "small pool done"
 timeout -k 10 120 tools/valu_peak > $OUT/valu_peak.jsonl 2>&1; echo "valu_peak done"
 echo done

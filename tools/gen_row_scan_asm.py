@@ -53,9 +53,9 @@ def scan_asm():
             a(f"ds_read_b32 {data[e]}, {addr[e]} offset:%c[TOFF]")
 
     def far_process(pc, data, newer):   # newer: loads issued after this chunk's (the next chunk's prefetch)
+        a(f"s_waitcnt lgkmcnt({newer})")   # (one wait for the four: they were issued a chunk ago and return together)
         for e in range(KC):
             p = PAIR[e & 1]
-            a(f"s_waitcnt lgkmcnt({newer + KC - 1 - e})")
             a(f"v_add3_u32 v{p + 1}, {data[e]}, %[Y], v{G(pc, e)}")
             a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:
@@ -108,7 +108,8 @@ def scan_asm():
             a(f"s_cmp_gt_i32 %[NEAR], {pc * KC + e}")
             a("s_cselect_b64 vcc, -1, 0")
             a("v_cndmask_b32_e32 %[BG], 0, %[Y], vcc")
-            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
+            if e == 0:
+                a("s_waitcnt lgkmcnt(0)")
             a(f"v_add3_u32 v{p + 1}, {data[e]}, %[BG], v{G(pc, e)}")
             a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:
@@ -122,7 +123,8 @@ def scan_asm():
         a(f"Lnr{pc}_%=:")
         for e in range(KC):   # row i-1 only
             p = PAIR[e & 1]
-            a(f"s_waitcnt lgkmcnt({KC - 1 - e})")
+            if e == 0:
+                a("s_waitcnt lgkmcnt(0)")
             a(f"v_add_u32 v{p + 1}, {data[e]}, v{G(pc, e)}")
             a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:

@@ -13,8 +13,9 @@ ROOT = Path(__file__).resolve().parent.parent
 RAW = ROOT / "gpurun_out" / "profiles_raw"
 OUT = ROOT / "profiles"
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
-kLaunchChecks = 134217728.0            # 2^27 pairs: one full launch
 kProbeChecks = 65536.0 * 65536.0       # the counter passes run the bench itself: one step of the 65,536-primer pool
+kLaunchesPerStep = 9.0                 # ... which the engine cuts into nine equal first-stage launches (capi.cpp kChunkPairs)
+kLaunchChecks = kProbeChecks / kLaunchesPerStep   # the launch every per-launch figure below belongs to
 KERNEL = "k_pairs_row"
 KERNEL_MATCH = "k_pairs_row<"   # the row-specialised first stage (thal_pairs_row.hip)
 # the commit whose kernels were measured: the last one that touched the kernel sources (pass it as argv[2] when
@@ -34,15 +35,17 @@ def pmc(sub):
             tot[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     n = len(dur) // max(len(tot), 1)
-    # the probe's launches are not all the same size (the last one of a pass is small): report the
-    # mean of one FULL-SIZE-EQUIVALENT launch = totals scaled to kLaunchChecks checks
-    scale = kLaunchChecks / (kProbeChecks / max(n, 1))
-    return ({k: sum(v) / len(v) * scale for k, v in tot.items()},
-            (sum(dur) / len(dur) * scale if dur else 0.0), n)
+    # mean per dispatch, as dispatched: the step's launches are equal (a multiple of kLaunchesPerStep of them)
+    assert n % int(kLaunchesPerStep) == 0, f"{sub}: {n} dispatches, expected a multiple of {kLaunchesPerStep}"
+    return ({k: sum(v) / len(v) for k, v in tot.items()}, (sum(dur) / len(dur) if dur else 0.0), n)
 
 
 shutil.copy(RAW / "bench_stats" / "bench_kernel_stats.csv", OUT / f"{ROUND}_bench_kernel_stats.csv")
 shutil.copy(RAW / "stage_a_stats" / "stagea_kernel_stats.csv", OUT / f"{ROUND}_stage_a_kernel_stats.csv")
+(OUT / f"{ROUND}_stage_a_kernel_stats.commit").write_text(COMMIT + "\n")   # bench.py names it beside the imported figure
+sp = RAW / "small_pool_stats" / "smallpool_kernel_stats.csv"
+if sp.exists():
+    shutil.copy(sp, OUT / f"{ROUND}_small_pool_kernel_stats.csv")
 for sub, name in (("stage_b_stats", "stageb"), ("stage_b2k_stats", "stageb2k")):
     src = RAW / sub / f"{name}_kernel_stats.csv"
     if src.exists():
@@ -61,7 +64,7 @@ simd_quads = 1024.0 * c2["GRBM_GUI_ACTIVE"] / 8.0 / 4.0
 wave_slots = 1024.0 * 3.0   # 768-thread blocks: three waves per SIMD
 with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"# rocprofv3 --pmc (separate passes, tools/collect_profiles.sh) -- python3 bench.py --steps 1 --warmup 0 (the bench's own 65,536-primer pool); kernel {KERNEL},\n"
-            f"# mean per dispatch (2^27 checks = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
+            f"# mean per dispatch ({checks:.6g} checks = a ninth of the step = {int(waves)} wave-batches of 64 pairs). SQ_* cycle counters are in quad-cycles;\n"
             f"# GRBM_GUI_ACTIVE sums the 8 XCDs (/8 = {c2['GRBM_GUI_ACTIVE']/8e6:.1f} M cycles in {ms2:.2f} ms = {clock_ghz:.2f} GHz)\n")
     for name, (c, ms, n) in (("pass 1", (c1, ms1, n1)), ("pass 2", (c2, ms2, n2)), ("FETCH_SIZE [KB]", (cf, msf, nf)),
                              ("WRITE_SIZE [KB]", (cw, msw, nw))):
@@ -78,6 +81,8 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"wave cycles: active / issue-stalled / waiting   {c2['SQ_ACTIVE_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / "
             f"{c1['SQ_WAIT_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / {c1['SQ_WAIT_ANY'] / c1['SQ_WAVE_CYCLES']:.3f}\n")
     f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
+    f.write(f"VALU busy share of SIMD cycles              {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}   (SQ_ACTIVE_INST_VALU quad-cycles "
+            f"= SQ_INSTS_VALU x {c2['SQ_ACTIVE_INST_VALU'] / c1['SQ_INSTS_VALU']:.3f}: every VALU instruction holds its SIMD for one quad-cycle, whatever its class)\n")
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "round": int(ROUND[1:]), "commit": COMMIT,
@@ -86,10 +91,11 @@ hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": hbm, "checks_per_launch": checks,
-    "note": "scaled to one full launch of 2^27 ordered pairs; traffic = the 64-byte atomics that set conflict bits "
-            "(0.5 % of pairs), the list of pairs handed to the later stages (about 2 %, 8 B each), the per-pair register "
-            "spills of the three-wave shape (none inside the cell loop) and the per-row table builds; algorithmic bytes "
-            "per launch are about 21 MB"}, indent=1))
+    "algorithmic_bytes_per_launch": 8.0 * (65536.0 / kLaunchesPerStep + 65536.0) + checks / 8.0 + 4.0 * 65536.0 / kLaunchesPerStep,
+    "note": "per first-stage launch as dispatched (a ninth of the 65,536^2 step); traffic = the 64-byte atomics that set "
+            "conflict bits (0.5 % of pairs), the list of pairs handed to the later stages (about 2 %, 8 B each), the "
+            "per-pair register spills (two registers, outside the cell loop) and the per-row table builds; bench.py scales "
+            "the bytes per check to its own launch"}, indent=1))
 (OUT / "pmc_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "source": f"profiles/{ROUND}_pmc_{KERNEL}.txt",
     "valu_instructions_per_check": c1["SQ_INSTS_VALU"] / waves,
