@@ -176,6 +176,14 @@ def stage_a_line(eng, device):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / (2 * reps) * 1e3
         ev = float(np.mean([a.elapsed_time(b) for a, b in ev_ms]))
+        # both directions in ONE call (msspe_kmer_candidates_both_packed_dev: the second direction on a second stream
+        # from a second host thread), as the C++ pipeline runs stage A
+        eng.kmer_candidates_both_packed(d, n_rows, length, opt)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            both = eng.kmer_candidates_both_packed(d, n_rows, length, opt)
+        both_ms = (time.perf_counter() - t1) / reps * 1e3
+        both_equal = all(list(both[x][0]) == list(words[x]) for x in (0, 1))
     finally:
         eng.device_free(d)
     segments = n_rows * ((length - 500) // 250 + 1)
@@ -187,6 +195,7 @@ def stage_a_line(eng, device):
                                                     "candidate_lists_made": its[2], "idle": its[3]},
                 "algorithmic_bytes_per_direction": alg_bytes,
                 "algorithmic_bytes_per_segment": alg_bytes / segments,
+                "both_directions_one_call_ms": both_ms, "both_directions_one_call_equal": bool(both_equal),
                 "GBps": alg_bytes / (ms * 1e-3) / 1e9,
                 "frac_of_6.29TBps_copy_ceiling": alg_bytes / (ms * 1e-3) / 6.29e12,
                 "note": "ms_per_direction: host wall time per direction incl. the greedy loop's dependent launches and "

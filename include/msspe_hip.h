@@ -297,6 +297,13 @@ int msspe_device_put_rows_packed(msspe_ctx *ctx, const char *const *rows, const 
 int msspe_kmer_candidates_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
                                      const msspe_kmer_opt *opt, int direction,
                                      uint64_t *words_out, uint32_t *freq_out, int capacity, int *n_out);
+/* Both directions of one alignment in one call (the reference runs find_candidates_kmers twice, main.rs:673-690):
+ * direction 0 on the context's stream, direction 1 on a second stream of the context from a second host thread -- each
+ * direction is a chain of small dependent launches and host round trips, which overlap.  Same results as two
+ * msspe_kmer_candidates_packed_dev calls; msspe_kmer_trace and the stage_a_* infos then describe direction 0. */
+int msspe_kmer_candidates_both_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                          const msspe_kmer_opt *opt, uint64_t *words_fwd, uint32_t *freq_fwd, int *n_fwd,
+                                          uint64_t *words_rev, uint32_t *freq_rev, int *n_rev, int capacity);
 int msspe_segment_coverage_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
                                       const msspe_kmer_opt *opt, const uint64_t *fwd_words, int n_fwd,
                                       const uint64_t *rev_words, int n_rev, uint8_t *hit_out);

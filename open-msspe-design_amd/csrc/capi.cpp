@@ -96,6 +96,9 @@ struct msspe_ctx {
     size_t sort_cap = 0, sort_scratch_bytes = 0;
     std::string err;
     KmerStage kmer;
+    KmerStage kmer_rev;                // direction 1 of msspe_kmer_candidates_both_packed_dev (its own buffers and loop graph)
+    hipStream_t stream_rev = nullptr;  // ... and its stream
+    hipEvent_t ev_rev = nullptr;
     // optional profiling of the dominant kernel (k_pairs_fast) with HIP events on ctx->stream
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -386,9 +389,11 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "stage_a_graph") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->kmer.set_use_graph(num != 0);
+        ctx->kmer_rev.set_use_graph(num != 0);
     } else if (k == "stage_a_candidates") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->kmer.set_narrow_loop(num != 0);
+        ctx->kmer_rev.set_narrow_loop(num != 0);
     } else {
         return fail(ctx, MSSPE_ERR_ARG, "msspe_set_option: unknown option '" + k + "'");
     }
@@ -429,6 +434,12 @@ void msspe_destroy(msspe_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         ctx->kmer.release();
+        ctx->kmer_rev.release();
+        if (ctx->ev_rev) (void)hipEventDestroy(ctx->ev_rev);
+        if (ctx->stream_rev) {
+            (void)hipStreamSynchronize(ctx->stream_rev);
+            (void)hipStreamDestroy(ctx->stream_rev);
+        }
         for (auto &e : ctx->chem_cache)
         {
             if (e.d_pt) (void)hipFree(e.d_pt);
@@ -1216,6 +1227,39 @@ int msspe_kmer_candidates_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, i
     const int rc = ctx->kmer.run(view, n_seq, seq_len, *opt, direction, words_out, freq_out,
                                  capacity, n_out, ctx->stream, err);
     if (rc) return fail(ctx, rc, err);
+    return MSSPE_OK;
+}
+
+int msspe_kmer_candidates_both_packed_dev(msspe_ctx *ctx, const uint64_t *d_packed, int n_seq, size_t seq_len,
+                                          const msspe_kmer_opt *opt, uint64_t *words_fwd, uint32_t *freq_fwd, int *n_fwd,
+                                          uint64_t *words_rev, uint32_t *freq_rev, int *n_rev, int capacity)
+{
+    if (!ctx) return MSSPE_ERR_ARG;
+    if (!d_packed || !opt || !words_fwd || !freq_fwd || !n_fwd || !words_rev || !freq_rev || !n_rev || capacity < 0)
+        return fail(ctx, MSSPE_ERR_ARG, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->stream_rev) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_rev, hipStreamNonBlocking));
+    if (!ctx->ev_rev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_rev, hipEventDisableTiming));
+    // the second stream starts behind whatever the context's stream holds (the upload of the alignment)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_rev, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream_rev, ctx->ev_rev, 0));
+    const SeqView view{nullptr, d_packed, seq_len};
+    std::string err0, err1;
+    int rc0 = MSSPE_OK, rc1 = MSSPE_OK;
+    // The two directions are independent (main.rs:673-690 runs them one after the other); each is a chain of small
+    // dependent launches with host round trips, so two host threads on two streams overlap them almost entirely.
+    std::thread rev([&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            rc1 = MSSPE_ERR_DEVICE;
+            err1 = "hipSetDevice failed";
+            return;
+        }
+        rc1 = ctx->kmer_rev.run(view, n_seq, seq_len, *opt, 1, words_rev, freq_rev, capacity, n_rev, ctx->stream_rev, err1);
+    });
+    rc0 = ctx->kmer.run(view, n_seq, seq_len, *opt, 0, words_fwd, freq_fwd, capacity, n_fwd, ctx->stream, err0);
+    rev.join();
+    if (rc0) return fail(ctx, rc0, err0);
+    if (rc1) return fail(ctx, rc1, "direction 1: " + err1);
     return MSSPE_OK;
 }
 

@@ -347,6 +347,36 @@ std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const DeviceAlignm
     return out;
 }
 
+// Both directions in one engine call (msspe_kmer_candidates_both_packed_dev: two streams, two host threads); what the
+// reference gets from its two find_candidates_kmers calls, main.rs:673-690.
+std::pair<std::vector<KmerFrequency>, std::vector<KmerFrequency>> find_candidates_kmers_both(
+    Engine &eng, const DeviceAlignment &aln, const ProgramConfig &cfg, int segment_size, int overlap_size, int window_size)
+{
+    if (overlap_size < window_size)   // main.rs:201-203
+        throw Panic("Overlap windows size must be greater or equal than search windows size");
+    std::pair<std::vector<KmerFrequency>, std::vector<KmerFrequency>> out;
+    if (aln.rows() == 0) return out;
+    msspe_kmer_opt opt{segment_size, overlap_size, window_size, cfg.primer_config.kmer_size,
+                       cfg.max_iterations, cfg.max_mismatch_segments};
+    const int cap = std::max(1, cfg.max_iterations);
+    std::vector<uint64_t> words[2] = {std::vector<uint64_t>((size_t)cap), std::vector<uint64_t>((size_t)cap)};
+    std::vector<uint32_t> freq[2] = {std::vector<uint32_t>((size_t)cap), std::vector<uint32_t>((size_t)cap)};
+    int n[2] = {0, 0};
+    const int rc = msspe_kmer_candidates_both_packed_dev(eng.ctx(), aln.device(), aln.rows(), aln.length(), &opt,
+                                                         words[0].data(), freq[0].data(), &n[0], words[1].data(),
+                                                         freq[1].data(), &n[1], cap);
+    if (rc) eng.fail(rc);
+    std::vector<char> buf((size_t)opt.kmer_size + 1);
+    for (int d = 0; d < 2; ++d) {
+        auto &dst = d ? out.second : out.first;
+        for (int i = 0; i < n[d]; ++i) {
+            msspe_unpack_oligo(words[d][(size_t)i], opt.kmer_size, buf.data());
+            dst.push_back({std::string(buf.data()), (uint8_t)(d ? SEQ_DIR_REV : SEQ_DIR_FWD), freq[d][(size_t)i]});
+        }
+    }
+    return out;
+}
+
 std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
                                                  uint8_t direction, const ProgramConfig &cfg,
                                                  int segment_size, int overlap_size, int window_size)
@@ -804,10 +834,9 @@ int run(const Args &args, std::string &stdout_text)
     Engine &eng = *eng_owner;
     const DeviceAlignment aln(eng, records);   // one upload for stage A (both directions) and the report
     timer.lap("engine + alignment upload");
-    const auto cand_f = find_candidates_kmers(eng, aln, SEQ_DIR_FWD, cfg, args.window_size,
-                                              args.overlap_size, args.search_windows_size);
-    const auto cand_r = find_candidates_kmers(eng, aln, SEQ_DIR_REV, cfg, args.window_size,
-                                              args.overlap_size, args.search_windows_size);
+    const auto cand_both = find_candidates_kmers_both(eng, aln, cfg, args.window_size, args.overlap_size,
+                                                      args.search_windows_size);
+    const auto &cand_f = cand_both.first, &cand_r = cand_both.second;
     timer.lap("stage A (both directions)");
     const auto stats_f = get_kmer_stats(eng, cand_f, cfg);
     const auto stats_r = get_kmer_stats(eng, cand_r, cfg);

@@ -152,6 +152,8 @@ private:
 std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const std::vector<SequenceRecord> &records,
                                                  uint8_t direction, const ProgramConfig &cfg,
                                                  int segment_size, int overlap_size, int window_size);
+std::pair<std::vector<KmerFrequency>, std::vector<KmerFrequency>> find_candidates_kmers_both(
+    Engine &eng, const DeviceAlignment &aln, const ProgramConfig &cfg, int segment_size, int overlap_size, int window_size);
 std::vector<KmerFrequency> find_candidates_kmers(Engine &eng, const DeviceAlignment &aln, uint8_t direction,
                                                  const ProgramConfig &cfg, int segment_size,
                                                  int overlap_size, int window_size);

@@ -22,6 +22,7 @@ EXPORTS = [
     "msspe_oligo_stats_dev", "msspe_oligo_stats",
     "msspe_kmer_candidates", "msspe_kmer_candidates_dev", "msspe_round_g_f32",
     "msspe_packed_row_words", "msspe_device_put_rows_packed", "msspe_kmer_candidates_packed_dev",
+    "msspe_kmer_candidates_both_packed_dev",
     "msspe_segment_coverage_packed_dev",
     "msspe_round_fixed_f32", "msspe_g_cut",
     "msspe_group_create", "msspe_group_destroy", "msspe_group_last_error", "msspe_group_size",
@@ -139,6 +140,8 @@ def load_library() -> C.CDLL:
                                         vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.msspe_kmer_candidates_dev.argtypes = L.msspe_kmer_candidates.argtypes
     L.msspe_kmer_candidates_packed_dev.argtypes = L.msspe_kmer_candidates.argtypes
+    L.msspe_kmer_candidates_both_packed_dev.argtypes = [vp, vp, C.c_int, C.c_size_t, C.POINTER(KmerOpt), vp, vp,
+                                                        C.POINTER(C.c_int), vp, vp, C.POINTER(C.c_int), C.c_int]
     L.msspe_packed_row_words.restype = C.c_size_t
     L.msspe_packed_row_words.argtypes = [C.c_size_t]
     L.msspe_device_put_rows_packed.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t,
@@ -426,6 +429,22 @@ class Engine:
             words.ctypes.data, freqs.ctypes.data, cap, C.byref(n_out)))
         m = n_out.value
         return [unpack_oligo(w, opt.kmer_size) for w in words[:m]], freqs[:m].copy()
+
+
+def _both(self, d_packed: int, n_seq: int, seq_len: int, opt: KmerOpt, capacity: int | None = None):
+    """Stage A, both directions of a packed alignment at once (msspe_kmer_candidates_both_packed_dev).
+    Returns ((words, freqs) of direction 0, (words, freqs) of direction 1)."""
+    cap = max(1, opt.max_iterations if capacity is None else capacity)
+    w = [np.zeros(cap, dtype=np.uint64) for _ in range(2)]
+    f = [np.zeros(cap, dtype=np.uint32) for _ in range(2)]
+    n = [C.c_int(0), C.c_int(0)]
+    self._check(self.L.msspe_kmer_candidates_both_packed_dev(
+        self.ptr, C.c_void_p(d_packed), n_seq, seq_len, C.byref(opt), w[0].ctypes.data, f[0].ctypes.data, C.byref(n[0]),
+        w[1].ctypes.data, f[1].ctypes.data, C.byref(n[1]), cap))
+    return tuple(([unpack_oligo(x, opt.kmer_size) for x in w[d][:n[d].value]], f[d][:n[d].value].copy()) for d in (0, 1))
+
+
+Engine.kmer_candidates_both_packed = _both
 
 
 def group_rows(n: int, n_members: int, member: int) -> np.ndarray:

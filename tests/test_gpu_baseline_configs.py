@@ -202,6 +202,13 @@ def test_config2_10000_genomes_both_directions_equal_the_full_size_oracle_fixtur
                     tr = eng.kmer_trace()
                     assert len(tr) == len(want)
                     kinds |= set(tr[:, 1].tolist())
+        # both directions in one call (two streams, two host threads): the same lists, called twice (the second call
+        # reuses both directions' loop graphs)
+        for _ in range(2):
+            both = eng.kmer_candidates_both_packed(d_rows, genomes.shape[0], genomes.shape[1], opt)
+            for direction in (0, 1):
+                assert list(zip(both[direction][0], both[direction][1].tolist())) == \
+                    [(w, f) for w, f in fx["winners"][str(direction)]], direction
         eng.device_free(d_rows)
     finally:
         eng.close()
