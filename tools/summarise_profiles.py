@@ -41,6 +41,12 @@ def pmc(sub):
 
 
 shutil.copy(RAW / "bench_stats" / "bench_kernel_stats.csv", OUT / f"{ROUND}_bench_kernel_stats.csv")
+bd = RAW / "bench_default_stats" / "benchdef_kernel_stats.csv"
+if bd.exists():
+    shutil.copy(bd, OUT / f"{ROUND}_bench_default_kernel_stats.csv")
+    dl = [l for l in open(RAW / "bench_default_stdout.log") if l.startswith('{"metric"')]
+    if dl:
+        (OUT / f"{ROUND}_bench_default_line.json").write_text(dl[-1])
 shutil.copy(RAW / "stage_a_stats" / "stagea_kernel_stats.csv", OUT / f"{ROUND}_stage_a_kernel_stats.csv")
 (OUT / f"{ROUND}_stage_a_kernel_stats.commit").write_text(COMMIT + "\n")   # bench.py names it beside the imported figure
 sp = RAW / "small_pool_stats" / "smallpool_kernel_stats.csv"
@@ -86,7 +92,7 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "round": int(ROUND[1:]), "commit": COMMIT,
-    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-stage-a --no-stage-b --no-cpu-baseline",
+    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-stage-a --no-stage-b --no-cpu-baseline --no-small-pool",
     "launches_sampled": nf,
     "FETCH_SIZE_KB_per_launch": cf["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": cw["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE taken as is",
