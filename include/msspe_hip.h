@@ -322,7 +322,10 @@ int msspe_device_free(msspe_ctx *ctx, void *device);
  * merges the per-primer conflict counts; bitmap rows and edge lists stay with their member until the host call
  * collects them.  Rows are dealt out in groups of 256, round robin (row r belongs to member (r / 256) mod N), so
  * that every member gets a sample of the whole pool whatever its order (msspe_group_rows lists a member's rows).
- * Results are identical to the single-context calls.
+ * Results are identical to the single-context calls (tests/test_gpu_group.py: members that share one card -- the
+ * device-copy transport -- and RCCL as a group of one rank).  NOT YET VERIFIED ON HARDWARE: two or more DISTINCT
+ * devices (grouped ncclAllGather / ncclAllReduce on N communicators from one thread, peer access, cross-device copies);
+ * no multi-GPU node has been reachable from the build, the two-device test skips on one card.
  *
  * transport: "auto" (NULL) | "rccl" | "device-copy".  "rccl": RCCL over xGMI, librccl.so loaded when the group is
  * made, needs distinct devices.  "device-copy": device-to-device copies and a summing kernel -- for members that
