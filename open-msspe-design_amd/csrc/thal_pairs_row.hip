@@ -56,6 +56,8 @@ static constexpr int kRowK = ROWK;                      // longest oligo of this
 // operands carry explicit register ranges, the scan one generated block (tools/gen_row_scan_asm.py ->
 // row_scan_pinned.inc: register map and reasons there).  The other instances leave the tuples to the allocator.
 static constexpr bool kPin = ROWK == 13 && ROWT == 768 && ROWS == 52 && ROWOOB;
+// ... and so do the 14- and 15-base instances (64 slots as two v32i per plane, 256 VGPRs, clamped table addresses)
+static constexpr bool kPin64 = ROWS == 64 && ROWT == 512 && !ROWOOB;
 static constexpr int kRowThreads = ROWT, kRowSlots = ROWS;   // 13 bases: 768 threads (three waves per SIMD), 52 stored cells per pair
 static constexpr int kRowL2 = kRowK - 1;                // l2 = j - 1 - jj = 0 .. k - 2
 static constexpr int kRowR = kRowK + 1;                 // digits of the row index: 14 i + (i - ii) at 13 bases
@@ -319,6 +321,32 @@ static __device__ __forceinline__ void pin_publish(v32i &Ga, v32i &Wa, v16i &Gb,
                  : "m0");
 }
 
+static __device__ __forceinline__ PinScan pin_scan64(const v32i Ga, const v32i Wa, const v32i Gb, const v32i Wb, const RCell &c,
+                                              int n_far, int n_run, int near_from)
+{
+    PinScan r;
+    int a0, a1, a2, a3, t0, t1, t2, t3;
+    asm volatile(MSSPE_ROW64_SCAN_ASM
+                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), [BG] "=&v"(r.bestG), [BW] "=&v"(r.bestW),
+                   [B2] "=&v"(r.G2), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
+                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [NFAR] "s"(n_far), [NRUN] "s"(n_run), [NEAR] "s"(near_from),
+                   [TOFF] "n"((int)offsetof(SharedRow, T)), [INIT] "n"(kRowInit), [TB] "n"(kRowTBytes),
+                   MSSPE_ROW64_TUPLES_IN(Ga, Gb, Wa, Wb)
+                 : MSSPE_ROW64_SCAN_CLOBBERS);
+    return r;
+}
+static __device__ __forceinline__ void pin_publish64(v32i &Ga, v32i &Wa, v32i &Gb, v32i &Wb, int slot, int G0s, int Wcell)
+{
+    asm volatile("s_set_gpr_idx_on %[SLOT], gpr_idx(DST)\n\t"
+                 "v_mov_b32 v%c[G0], %[G]\n\t"
+                 "v_mov_b32 v%c[W0], %[W]\n\t"
+                 "s_set_gpr_idx_off"
+                 : MSSPE_ROW64_TUPLES_INOUT(Ga, Gb, Wa, Wb)
+                 : [G] "v"(G0s), [W] "v"(Wcell), [SLOT] "s"(slot), [G0] "n"(MSSPE_ROW64_G0), [W0] "n"(MSSPE_ROW64_W0)
+                 : "m0");
+}
+
 // thal ANY for the lane's pair (oligo 1 = the block's row primer).  !active: idle lane.  n_slots: the slots the
 // wave's rows take (all rows but the last, padded to the widest lane); wmax4: the widest lane's count of each base.
 template <int NS>
@@ -382,6 +410,13 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         // the code that catches it
         if constexpr (kPin) {
             const PinScan ps = pin_scan(Ga, Wa, Gb, Wb, Gc, Wc, rc, start_im1 / kC, (row_start + kC - 1) / kC, start_im1);
+            rb.GW = __hiloint2double(ps.bestG, ps.bestW);
+            rb.G2 = ps.G2;
+            stk.G = ps.stkG;
+            stk.W = ps.stkW;
+            sm.stHave = ps.stHave;
+        } else if constexpr (kPin64) {
+            const PinScan ps = pin_scan64(Ga, Wa, Gb, Wb, rc, start_im1 / kC, (row_start + kC - 1) / kC, start_im1);
             rb.GW = __hiloint2double(ps.bestG, ps.bestW);
             rb.G2 = ps.G2;
             stk.G = ps.stkG;
@@ -471,6 +506,8 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         //  nothing reads it, no row follows and the walk back only matches predecessors)
         if constexpr (kPin) {
             if (slot < NS) pin_publish(Ga, Wa, Gb, Wb, Gc, Wc, slot, G0s, Wcell);   // (slot 52: cells of the last row of a full table, written nowhere)
+        } else if constexpr (kPin64) {
+            if (slot < NS) pin_publish64(Ga, Wa, Gb, Wb, slot, G0s, Wcell);
         } else
         if (slot < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[slot & 31] = G0s;

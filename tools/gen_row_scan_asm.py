@@ -22,11 +22,29 @@ Register map (168 VGPRs = three waves per SIMD):
     everything else: the compiler's
 usage: tools/gen_row_scan_asm.py > open-msspe-design_amd/csrc/row_scan_pinned.inc
 """
-NS, KC = 52, 4
-G2 = 57
-PAIR = (58, 60)
-G0, W0 = 62, 114
-ACC = 166
+KC = 4
+
+
+class Cfg:
+    def __init__(self, name, ns, g2, pairs, g0, w0, acc, tuples, clamp):
+        self.name, self.ns, self.g2, self.pairs, self.g0, self.w0, self.acc = name, ns, g2, pairs, g0, w0, acc
+        self.tuples = tuples      # [(first register, length)] of Ga, Gb, (Gc), Wa, Wb, (Wc) in operand order
+        self.clamp = clamp        # the table address is clamped onto the "not available" entry behind the table
+
+
+# 13 bases: 768 threads, 168 VGPRs, 52 slots as v32i + v16i + v4i per plane; addresses need no clamp (kRowZero)
+ROW13 = Cfg("ROW13", 52, 57, (58, 60), 62, 114, 166,
+            [(62, 32), (94, 16), (110, 4), (114, 32), (146, 16), (162, 4)], False)
+# 14 / 15 bases: 512 threads, 256 VGPRs, 64 slots as two v32i per plane; clamped addresses
+#     v120 .. v183  G[0 .. 63], v184 .. v247  W[0 .. 63], v[248:249] running minimum, v[250:251] v[252:253] pairs, v254 G2
+ROW64 = Cfg("ROW64", 64, 254, (250, 252), 120, 184, 248,
+            [(120, 32), (152, 32), (184, 32), (216, 32)], True)
+NS = G2 = PAIR = G0 = W0 = ACC = CLAMP = None
+
+
+def use(cfg):
+    global NS, G2, PAIR, G0, W0, ACC, CLAMP
+    NS, G2, PAIR, G0, W0, ACC, CLAMP = cfg.ns, cfg.g2, cfg.pairs, cfg.g0, cfg.w0, cfg.acc, cfg.clamp
 
 
 def scan_asm():
@@ -49,6 +67,9 @@ def scan_asm():
             a(f"v_sub_u32 {addr[e]}, %[C], v{W(pc, e)}")
         for e in range(KC):
             a(f"v_lshrrev_b32 {addr[e]}, 15, {addr[e]}")
+        if CLAMP:   # a predecessor that is not up-left of the cell: onto the "not available" entry behind the table
+            for e in range(KC):
+                a(f"v_min_u32 {addr[e]}, %[TB], {addr[e]}")
         for e in range(KC):
             a(f"ds_read_b32 {data[e]}, {addr[e]} offset:%c[TOFF]")
 
@@ -147,15 +168,16 @@ def cstr(lines):
     return "\n".join('    "' + l + '\\n\\t"' for l in lines)
 
 
-print("// GENERATED by tools/gen_row_scan_asm.py -- do not edit (see that file for the why and the register map)")
-print(f"#define MSSPE_ROW13_G0 {G0}")
-print(f"#define MSSPE_ROW13_W0 {W0}")
-print("#define MSSPE_ROW13_SCAN_ASM \\")
-print(" \\\n".join('    "' + l + '\\n\\t"' for l in scan_asm()))
-print("#define MSSPE_ROW13_SCAN_CLOBBERS " + ", ".join(f'"v{r}"' for r in clobbers()) + ', "vcc", "scc", "m0", "memory"')
-print('#define MSSPE_ROW13_TUPLES_IN(Ga, Gb, Gc, Wa, Wb, Wc) "{v[%d:%d]}"(Ga), "{v[%d:%d]}"(Gb), "{v[%d:%d]}"(Gc), '
-      '"{v[%d:%d]}"(Wa), "{v[%d:%d]}"(Wb), "{v[%d:%d]}"(Wc)' % (G0, G0 + 31, G0 + 32, G0 + 47, G0 + 48, G0 + 51,
-                                                                W0, W0 + 31, W0 + 32, W0 + 47, W0 + 48, W0 + 51))
-print('#define MSSPE_ROW13_TUPLES_INOUT(Ga, Gb, Gc, Wa, Wb, Wc) "+{v[%d:%d]}"(Ga), "+{v[%d:%d]}"(Gb), "+{v[%d:%d]}"(Gc), '
-      '"+{v[%d:%d]}"(Wa), "+{v[%d:%d]}"(Wb), "+{v[%d:%d]}"(Wc)' % (G0, G0 + 31, G0 + 32, G0 + 47, G0 + 48, G0 + 51,
-                                                                   W0, W0 + 31, W0 + 32, W0 + 47, W0 + 48, W0 + 51))
+print("// GENERATED by tools/gen_row_scan_asm.py -- do not edit (see that file for the why and the register maps)")
+for cfg in (ROW13, ROW64):
+    use(cfg)
+    n = cfg.name
+    print(f"#define MSSPE_{n}_G0 {G0}")
+    print(f"#define MSSPE_{n}_W0 {W0}")
+    print(f"#define MSSPE_{n}_SCAN_ASM \\")
+    print(" \\\n".join('    "' + l + '\\n\\t"' for l in scan_asm()))
+    print(f"#define MSSPE_{n}_SCAN_CLOBBERS " + ", ".join(f'"v{r}"' for r in clobbers()) + ', "vcc", "scc", "m0", "memory"')
+    names = ["Ga", "Gb", "Gc", "Wa", "Wb", "Wc"] if len(cfg.tuples) == 6 else ["Ga", "Gb", "Wa", "Wb"]
+    for kind, pre in (("IN", ""), ("INOUT", "+")):
+        print(f"#define MSSPE_{n}_TUPLES_{kind}(" + ", ".join(names) + ") " +
+              ", ".join('"%s{v[%d:%d]}"(%s)' % (pre, r0, r0 + ln - 1, nm) for (r0, ln), nm in zip(cfg.tuples, names)))
