@@ -68,6 +68,7 @@ struct EngineOptions {
     int split_lanes = 0;      // 0: by oligo length; 2 / 4 / 8
     bool row_oob = true;      // the row-specialised first stage (it reads LDS beyond its allocation: thal_pairs_row.hip) may run
     bool split_list = true;   // short oligos: tables too large for the integer list stage go to the split kernel's list mode
+    bool short_chain = true;  // screens of up to 2^23 pairs: integer list stage -> one wave per pair (no register-table stages between)
     int self_lane_from = 81920;   // oligos per call from which SELF_ANY / SELF_END run one lane per oligo (msspe_oligo_stats_dev)
 };
 
@@ -380,6 +381,9 @@ int msspe_set_option(msspe_ctx *ctx, const char *key, const char *value)
     } else if (k == "split_list") {
         if (!is_num || num < 0 || num > 1) return bad();
         ctx->opt.split_list = num != 0;
+    } else if (k == "short_chain") {
+        if (!is_num || num < 0 || num > 1) return bad();
+        ctx->opt.short_chain = num != 0;
     } else if (k == "self_lane_from") {
         if (!is_num || num < 0) return bad();
         ctx->opt.self_lane_from = (int)num;
@@ -664,6 +668,8 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
     // Overflow pairs are collected over several launches and finished together: the list kernels
     // have a fixed latency floor, and list_cap entries cannot be overrun by list_cap / kChunkPairs
     // launches even if every pair overflowed.
+    // small screens (the reference's are at most 2,000^2): the short chain behind the integer list stage
+    const bool short_chain = wave_ok && ctx->opt.short_chain && (long)(row1 - row0) * (long)ncols <= (1L << 23);
     auto flush = [&]() -> int {
         PairKernelArgs a;
         a.ft = ce->d_ft;
@@ -719,6 +725,22 @@ static int cross_dimer_impl(msspe_ctx *ctx, const uint64_t *d_pool, int n, int k
             HIP_TRY(ctx, launch_pairs_int_list(a, ce->d_it, in_list, ctx->ovf_count + in_c, ctx->d_reasons,
                                                ctx->n_cu, ctx->stream));
             advance();
+            if (short_chain) {
+                // a reference-sized screen: what the integer list stage leaves (some ten thousand pairs) goes straight to
+                // one wave per pair -- each of the three register-table stages in between has a latency floor of 0.4 ...
+                // 0.6 ms whatever its list holds, the wave kernel takes 0.13 ms + 16 ns per pair
+                a.overflow_list = out_list;
+                a.overflow_count = ctx->ovf_count + out_c;
+                HIP_TRY(ctx, launch_pairs_wave(a, ce->d_st, in_list, ctx->ovf_count + in_c, ctx->stream));
+                g.list = out_list;
+                g.list_count = ctx->ovf_count + out_c;
+                g.n_work = kListCap;
+                HIP_TRY(ctx, launch_dimer_generic(g, ctx->stream));
+                hipLaunchKernelGGL(k_accumulate_overflow, dim3(1), dim3(64), 0, ctx->stream, ctx->ovf_count,
+                                   ctx->d_ovf_total, (uint32_t)kListCap);
+                HIP_TRY(ctx, hipMemsetAsync(ctx->ovf_count, 0, 8 * sizeof(uint32_t), ctx->stream));
+                return MSSPE_OK;
+            }
             if (ce->split_max_k >= k && ctx->opt.split_list) {
                 // (1b) tables beyond the list stage's 63 stored cells: two lanes per pair, still exact integers
                 //      (marked entries -- ties -- pass through to the f64 kernels)

@@ -21,6 +21,10 @@ def main():
     sizes = [int(x) for x in args] or [2000]
     K = 13
     eng = m.Engine(0)
+    import os
+    for kv in os.environ.get("MSSPE_PROBE_OPTIONS", "").split(","):
+        if kv:
+            eng.set_option(*kv.split("="))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     chem = m.Chem.ntthal()
     for n in sizes:
