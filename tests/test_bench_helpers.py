@@ -23,3 +23,12 @@ def test_stage_a_roofline_comes_from_the_committed_kernel_stats():
     assert 1.0 < roof["kernel_ms_per_direction"] < 20.0
     assert abs(roof["achieved"] - alg_bytes / (roof["kernel_ms_per_direction"] * 1e-3) / 1e9) < 1e-6
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+
+
+def test_generated_scan_is_what_the_generator_writes():
+    """open-msspe-design_amd/csrc/row_scan_pinned.inc (the row kernels' predecessor scan as inline asm) is generated:
+    the committed file must be the generator's output, byte for byte."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_row_scan_asm.py")], capture_output=True, text=True, check=True)
+    assert out.stdout == (ROOT / "open-msspe-design_amd" / "csrc" / "row_scan_pinned.inc").read_text()
