@@ -298,11 +298,11 @@ static __device__ __forceinline__ PinScan pin_scan(const v32i Ga, const v32i Wa,
                                             const v4i Wc, const RCell &c, int n_far, int n_run, int near_from)
 {
     PinScan r;
-    int a0, a1, a2, a3, t0, t1, t2, t3;
+    int a0, a1, a2, a3, t0, t1, t2, t3, yt;
     asm volatile(MSSPE_ROW13_SCAN_ASM
-                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), [BG] "=&v"(r.bestG), [BW] "=&v"(r.bestW),
-                   [B2] "=&v"(r.G2), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
-                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), MSSPE_ROW13_ACC_OUT(r.bestG, r.bestW, r.G2),
+                   [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
+                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [yt] "=&v"(yt)
                  : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [NFAR] "s"(n_far), [NRUN] "s"(n_run), [NEAR] "s"(near_from),
                    [TOFF] "n"((int)offsetof(SharedRow, T)), [INIT] "n"(kRowInit), MSSPE_ROW13_TUPLES_IN(Ga, Gb, Gc, Wa, Wb, Wc)
                  : MSSPE_ROW13_SCAN_CLOBBERS);
@@ -325,11 +325,11 @@ static __device__ __forceinline__ PinScan pin_scan64(const v32i Ga, const v32i W
                                               int n_far, int n_run, int near_from)
 {
     PinScan r;
-    int a0, a1, a2, a3, t0, t1, t2, t3;
+    int a0, a1, a2, a3, t0, t1, t2, t3, yt;
     asm volatile(MSSPE_ROW64_SCAN_ASM
-                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), [BG] "=&v"(r.bestG), [BW] "=&v"(r.bestW),
-                   [B2] "=&v"(r.G2), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
-                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [SG] "=&v"(r.stkG), [SW] "=&v"(r.stkW), [HV] "=&s"(r.stHave), MSSPE_ROW64_ACC_OUT(r.bestG, r.bestW, r.G2),
+                   [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0),
+                   [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [yt] "=&v"(yt)
                  : [C] "v"(c.C), [Y] "v"(c.yTS), [IDX] "s"(c.idxStk), [NFAR] "s"(n_far), [NRUN] "s"(n_run), [NEAR] "s"(near_from),
                    [TOFF] "n"((int)offsetof(SharedRow, T)), [INIT] "n"(kRowInit), [TB] "n"(kRowTBytes),
                    MSSPE_ROW64_TUPLES_IN(Ga, Gb, Wa, Wb)

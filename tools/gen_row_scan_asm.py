@@ -14,11 +14,11 @@ visit: sub, lshr, [ds_read], add3, mov, med3, min_f64 -- with one exit and no co
 any slot (GPR-index mode over the whole 52-register plane, tuple boundaries or not).
 
 Register map (168 VGPRs = three waves per SIMD):
-    v57           G2: runner-up of the running minimum            (scan-internal: clobbered, free outside the scan)
+    v57           G2: runner-up of the running minimum            (the scan's output, where it stands)
     v58:59, v60:61  operand pairs (value : word) of v_min_f64     (scan-internal)
     v62 .. v113   G[0 .. 51]   slot values (+ kRowZero)           = Ga v[62:93], Gb v[94:109], Gc v[110:113]
     v114 .. v165  W[0 .. 51]   slot words                         = Wa v[114:145], Wb v[146:161], Wc v[162:165]
-    v166:167      running minimum (value : word)                  (scan-internal)
+    v166:167      running minimum (value : word)                  (the scan's output, where it stands)
     everything else: the compiler's
 usage: tools/gen_row_scan_asm.py > open-msspe-design_amd/csrc/row_scan_pinned.inc
 """
@@ -128,10 +128,10 @@ def scan_asm():
             p = PAIR[e & 1]
             a(f"s_cmp_gt_i32 %[NEAR], {pc * KC + e}")
             a("s_cselect_b64 vcc, -1, 0")
-            a("v_cndmask_b32_e32 %[BG], 0, %[Y], vcc")
+            a("v_cndmask_b32_e32 %[yt], 0, %[Y], vcc")
             if e == 0:
                 a("s_waitcnt lgkmcnt(0)")
-            a(f"v_add3_u32 v{p + 1}, {data[e]}, %[BG], v{G(pc, e)}")
+            a(f"v_add3_u32 v{p + 1}, {data[e]}, %[yt], v{G(pc, e)}")
             a(f"v_mov_b32 v{p}, v{W(pc, e)}")
             if e >= 1:
                 tail(e - 1)
@@ -152,16 +152,12 @@ def scan_asm():
                 tail(e - 1)
             stk(pc, e, addr)
         tail(KC - 1)
-    a("Ldone%=:")
-    a(f"v_mov_b32 %[BG], v{ACC + 1}")
-    a(f"v_mov_b32 %[BW], v{ACC}")
-    a(f"v_mov_b32 %[B2], v{G2}")
+    a("Ldone%=:")   # (the running minimum and its runner-up are the asm's outputs where they stand: MSSPE_*_ACC_OUT)
     return L
 
 
 def clobbers():
-    regs = [G2] + [PAIR[0], PAIR[0] + 1, PAIR[1], PAIR[1] + 1] + [ACC, ACC + 1]
-    return regs
+    return [PAIR[0], PAIR[0] + 1, PAIR[1], PAIR[1] + 1]
 
 
 def cstr(lines):
@@ -177,6 +173,7 @@ for cfg in (ROW13, ROW64):
     print(f"#define MSSPE_{n}_SCAN_ASM \\")
     print(" \\\n".join('    "' + l + '\\n\\t"' for l in scan_asm()))
     print(f"#define MSSPE_{n}_SCAN_CLOBBERS " + ", ".join(f'"v{r}"' for r in clobbers()) + ', "vcc", "scc", "m0", "memory"')
+    print(f'#define MSSPE_{n}_ACC_OUT(hi, lo, g2) "=&{{v{ACC + 1}}}"(hi), "=&{{v{ACC}}}"(lo), "=&{{v{G2}}}"(g2)')
     names = ["Ga", "Gb", "Gc", "Wa", "Wb", "Wc"] if len(cfg.tuples) == 6 else ["Ga", "Gb", "Wa", "Wb"]
     for kind, pre in (("IN", ""), ("INOUT", "+")):
         print(f"#define MSSPE_{n}_TUPLES_{kind}(" + ", ".join(names) + ") " +
