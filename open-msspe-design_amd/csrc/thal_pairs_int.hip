@@ -304,6 +304,19 @@ __device__ __forceinline__ IntResult run_pair_int(SH &sh, const ThalConsts &K, c
         //      at work is in its last row (wave_pairs), whose cells are nobody's predecessors: they all land in
         //      slot NS - 1, which nothing reads
         const int ps = min(slot, NS - 1);   // wave-uniform; slot NS - 1 is kept free for them (wave_pairs)
+        if constexpr (NS == 64) {
+            // list mode: the four tuples bound to fixed registers where they are written (explicit register ranges on
+            // the asm's operands, as in thal_pairs_row.hip): ONE indexed write per plane over the whole 64-register plane.
+            // Left to the allocator, a write into the upper tuples copied both of them to fresh registers and back
+            // (some sixty 64-bit moves per cell from slot 32 on -- half the cells of the tables this stage gets).
+            asm volatile("s_set_gpr_idx_on %[SLOT], gpr_idx(DST)\n\t"
+                         "v_mov_b32 v120, %[G]\n\t"
+                         "v_mov_b32 v184, %[W]\n\t"
+                         "s_set_gpr_idx_off"
+                         : "+{v[120:151]}"(Ga), "+{v[152:183]}"(Gb), "+{v[184:215]}"(Wa), "+{v[216:247]}"(Wb)
+                         : [G] "v"(G0), [W] "v"(Wcell), [SLOT] "s"(ps)
+                         : "m0");
+        } else
         if (ps < 32) {   // wave-uniform slot number: one indexed register write per plane
             Ga[ps & 31] = G0;
             Wa[ps & 31] = Wcell;
