@@ -66,7 +66,7 @@ _lib_override: Path | None = None
 
 
 def use_library(path) -> None:
-    """Development aid (tools/variant_build_file.sh): load another build of the library; call before the
+    """Development aid (A/B timing of two builds, tools/perf_probe.py MSSPE_PROBE_LIB): load another build of the library; call before the
     first Engine is created."""
     global _lib_override
     _lib_override = Path(path)
