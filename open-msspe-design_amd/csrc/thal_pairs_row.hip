@@ -169,15 +169,45 @@ static __device__ __forceinline__ KParts k_parts(unsigned K)
     p.n2 = (int)(rest & 3u);
     return p;
 }
-// coordinates of a slot word as one byte jj << 4 | ii (0xff: none)
-static __device__ __forceinline__ int word_cw(int W)
+// The predecessor byte of a cell (pred_lo / pred_hi), made from the predecessor's slot word once per cell; only the
+// walk back reads it, through sig_of_cw.  With kRowA = 772 = 768 + 4 (13 bases) K = 768 jj + 4 (ii + jj) + n2, so the
+// word's bits 25.. are 3 jj and its bits 19..23 ii + jj: the byte is 4 (3 jj) + (ii + jj) = 13 jj + ii, three
+// instructions.  Otherwise jj << 4 | ii by k_parts' division.  0xff: no predecessor (the word kNoPredW gives it).
+static constexpr bool kCompactCw = kRowA == 772;
+static constexpr int kNoPredW = kCompactCw ? (int)((56u << 25) | (31u << 19)) : (int)((unsigned)(15 * kRowA + 60) << 17);
+static_assert(15 * kRowA + 60 < (1 << 14), "kNoPredW is a positive 32-bit word");   // (cw_ok: checked below the struct)
+static __device__ __host__ __forceinline__ constexpr int word_cw(int W)
 {
-    const KParts p = k_parts((unsigned)W >> 17);
-    return (p.jj << 4) | p.ii;
+    if constexpr (kCompactCw) {
+        return (int)((((unsigned)W >> 25) << 2) + (((unsigned)W >> 19) & 31u));
+    } else {
+        const unsigned K = (unsigned)W >> 17;
+        const unsigned jj = (K * kRowDivMagic) >> 24;
+        return (int)((jj << 4) | ((K - jj * (unsigned)kRowA) >> 2));
+    }
 }
 // what the traceback compares: K without n2
 static __device__ __forceinline__ unsigned word_sig(int W) { return ((unsigned)W >> 17) & ~3u; }
-static __device__ __forceinline__ unsigned sig_of_cw(int cw) { return (unsigned)(cw >> 4) * (unsigned)kRowA + (unsigned)((cw & 15) << 2); }
+static __device__ __host__ __forceinline__ constexpr unsigned sig_of_cw(int cw)
+{
+    if constexpr (kCompactCw) {
+        const unsigned jj = ((unsigned)cw * 79u) >> 10;   // cw / 13 for cw < 169
+        return jj * (unsigned)(kRowA - 4 * 13) + ((unsigned)cw << 2);   // kRowA jj + 4 (cw - 13 jj)
+    } else {
+        return (unsigned)(cw >> 4) * (unsigned)kRowA + (unsigned)((cw & 15) << 2);
+    }
+}
+static constexpr bool cw_ok()
+{
+    for (int jj = 0; jj < kRowK; ++jj)
+        for (int ii = 0; ii < kRowK; ++ii)
+            for (int n2 = 0; n2 < 4; ++n2) {
+                const unsigned K = (unsigned)(jj * kRowA + 4 * ii + n2);
+                const int cw = word_cw((int)(K << 17) | 0x7fff);
+                if (cw == 0xff || (cw & ~0xff) || sig_of_cw(cw) != (K & ~3u)) return false;
+            }
+    return word_cw(kNoPredW) == 0xff && word_cw(kNoPredW | 0x7fff) == 0xff;
+}
 static __device__ __forceinline__ int word_h(int W) { return (W & 0x7fff) - kHBias; }
 // the f64 kernels' word (h << 14 | po << 8 | im1 << 4 | jm1) of pair_core.hpp's cand_* helpers;
 // po = pair base | 3' neighbour on oligo 1 << 2 | right neighbour on oligo 2 << 4
@@ -437,7 +467,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         //      of 10 cal/mol (h): T = A / B with A = 10 (h + 20 + rh), 620300 B = 20000 h - G + cq; the
         //      factor 10 drops out of A1 B0 > A0 B1
         // (every LDS read of the cell's own terms is issued here, in one group: one wait, not four)
-        int h0 = sh.h[b.idxL - kRowGBase], G0 = sh.g[b.idxL - kRowGBase], pred = 0xff, flags = 0, cell_soft = 0;
+        int h0 = sh.h[b.idxL - kRowGBase], G0 = sh.g[b.idxL - kRowGBase], predW = kNoPredW, flags = 0, cell_soft = 0;
         const int rh = sh.h[b.idxR - kRowGBase], gR = sh.g[b.idxR - kRowGBase], hwc = sh.h[b.wc - kRowGBase], gwc = sh.g[b.wc - kRowGBase];
         const double cq = sh.cq[b.idxR - FastTables::kEndR];
         const int pickG = pick_g;
@@ -453,7 +483,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
             if (lhs > rhs) {
                 h0 = h1;
                 G0 = G1;
-                pred = word_cw(stk.W);
+                predW = stk.W;
             }
         }
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
@@ -469,7 +499,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
                 flags |= ((hw > 0) & (__mul24(20000, hw) - best.G > -1000)) ? kDeferBad : 0;
                 h0 = hw;
                 G0 = best.G;
-                pred = word_cw(best.W);
+                predW = best.W;
             } else if (hw == h0) {
                 cell_soft = 0x100;
                 if (in) sh.soft[slot >> 5][threadIdx.x] |= 1u << (slot & 31);
@@ -477,6 +507,7 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
                 flags |= kDeferLoopEq;
             }
         }
+        const int pred = word_cw(predW);   // (once, behind both choices: the word is what they select)
         const int hb = h0 + kHBias;
         flags |= ((unsigned)hb > 0x7fffu) ? kDeferReplay : 0;   // enthalpy beyond the 15-bit field: hand the pair on
         const int Wcell = in ? ((int)((unsigned)(jm1 * kRowA + (im1 << 2) + ((b.po_c >> 4) & 3)) << 17) | (hb & 0x7fff))
@@ -905,6 +936,8 @@ using Row13 = RowKernel<13, 768, 52, true>;
 using Row14 = RowKernel<14, 512, 64, false>;
 using Row15 = RowKernel<15, 512, 64, false>;
 static_assert(Row13::div_magic_ok() && Row14::div_magic_ok() && Row15::div_magic_ok(), "K / kRowA by multiply-shift");
+static_assert(Row13::cw_ok() && Row14::cw_ok() && Row15::cw_ok(), "the predecessor byte names every cell, and 0xff none");
+static_assert(Row13::kCompactCw && !Row15::kCompactCw, "13 bases: the three-instruction byte");
 static_assert(Row13::kRowA == 772 && Row14::kRowA == 900 && Row15::kRowA == 964, "table strides");
 
 template <class RK>
