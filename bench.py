@@ -394,6 +394,17 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     strong = args.config == "pool1m"
+    if strong and rank == 0:
+        # a step of the 1,048,576 pool is minutes of queued launches behind one fence: say on stderr that the run is
+        # alive (a watchdog that sees no output for minutes takes a run for hung); stdout stays the one JSON line
+        import threading
+        t_alive = time.perf_counter()
+
+        def heartbeat():
+            while True:
+                time.sleep(60.0)
+                print(f"bench.py pool1m: running, {time.perf_counter() - t_alive:.0f} s", file=sys.stderr, flush=True)
+        threading.Thread(target=heartbeat, daemon=True).start()
     n = args.pool if args.pool else (1 << 20 if strong else pool_size_for(world))
     if not args.pool:
         n = (n // (64 * world)) * (64 * world)
