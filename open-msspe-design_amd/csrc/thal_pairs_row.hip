@@ -574,7 +574,6 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
     out.r.t = 0.0;
     out.r.conflict = false;
 
-    const int nch = (n_slots + kC - 1) / kC;
     const unsigned pick_ties = (unsigned)sh.pick[2][threadIdx.x];   // a second walk would be paid by the whole wave: handed on, unless (below)
     const unsigned long long softTie =
         (unsigned long long)sh.soft[0][threadIdx.x] | ((unsigned long long)sh.soft[1][threadIdx.x] << 32);
@@ -585,31 +584,62 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
     int H = 0, P = 0, dpath = 0;
     const int endW = sh.pick[1][threadIdx.x];
     {
-        // the picked cell (which may have no slot) opens the path; the walk goes on from its predecessor
+        // The picked cell (which may have no slot) opens the path; the walk goes on from its predecessor byte to that
+        // cell's, and so on: a step per cell of the LONGEST path of the wave, not one per slot of the table (the slot
+        // words live in registers, which a lane cannot index -- but all the walk needs of a cell is its predecessor
+        // byte, and the cell's slot follows from its coordinates: the first slot of its row, a wave-uniform table of
+        // bytes in four scalars, plus the number of earlier columns of oligo 2 with the same base).
+        unsigned rs_pack[4] = {0u, 0u, 0u, 0u};   // byte i: first slot of row i
+        {
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < kRowK; ++i) {   // (rows beyond the oligo's length: never looked up)
+                rs_pack[i >> 2] |= (unsigned)acc << (8 * (i & 3));
+                const int a_row = (int)((q.s1 >> (2 * i)) & 3u);
+                acc += (i < kRowK - 1) ? (int)((wmax4 >> (8 * (3 - a_row))) & 0xffu) : 0;
+            }
+        }
         const int end3 = sh.pick[3][threadIdx.x];
-        unsigned cur = sig_of_cw(end3 & 0xff);
-        bool done = out.r.none | ((end3 & 0xff) == 0xff);
+        int cw = end3 & 0xff;
+        bool done = out.r.none | (cw == 0xff);
         if (!out.r.none) {
             sh.path[0][threadIdx.x] = (unsigned short)((unsigned)endW >> 17);
             P = 1;
             dpath |= (end3 & 0x100) ? kDeferPathTie : 0;
         }
-        for (int pc_ = nch - 1; pc_ >= 0; --pc_) {
-            const int pc = __builtin_amdgcn_readfirstlane(pc_);
-            int W[kC];
-#pragma unroll
-            for (int e = 0; e < kC; ++e) W[e] = slot_of<NS>(Wa, Wb, Wc, pc * kC + e);
-#pragma unroll
-            for (int e = kC - 1; e >= 0; --e) {
-                const int slot = pc * kC + e;
-                const int pr = sh.pred(slot, threadIdx.x);
-                const bool hit = !done & (word_sig(W[e]) == cur);   // an empty slot matches no cell
-                if (hit) sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)((unsigned)W[e] >> 17);
-                dpath |= (hit & (((softTie >> slot) & 1ull) != 0ull)) ? kDeferPathTie : 0;
-                P += hit ? 1 : 0;
-                cur = hit ? sig_of_cw(pr) : cur;
-                done = done | (hit & (pr == 0xff));
+        const unsigned char *const pred_bytes = reinterpret_cast<const unsigned char *>(&sh);
+        constexpr int kOffLo = (int)offsetof(SharedRow, pred_lo), kOffHi = (int)offsetof(SharedRow, pred_hi) - kPredLo * kRowThreads;
+        for (int step = 0; step < kPathMax; ++step) {   // wave-uniform
+            if (__ballot(!done) == 0ull) break;
+            int ii, jj;
+            if constexpr (kCompactCw) {
+                jj = (int)(((unsigned)cw * 79u) >> 10);
+                ii = cw - 13 * jj;
+            } else {
+                jj = cw >> 4;
+                ii = cw & 15;
             }
+            const int b2 = 2 * jj;
+            const unsigned base = (q.s2 >> b2) & 3u;            // = 3 - s1[ii]: the cell is a complementary one
+            // the base in every 2-bit field below the cell's column (24-bit multiplies: the 32-bit one issues at a quarter
+            // of the rate; columns 0 .. 11 are all a 13-base oligo's cell can have before it)
+            unsigned rep = (unsigned)__mul24((int)base, 0x555555);
+            if constexpr (kRowK > 13) rep |= (unsigned)__mul24((int)base, 0x55) << 24;
+            const unsigned x = q.s2 ^ rep;
+            const unsigned differ = (x | (x >> 1)) & 0x55555555u & ((1u << b2) - 1u);   // earlier columns with another base
+            const int rank = jj - __popc(differ);
+            const unsigned sel = 0x0c0c0c00u | (unsigned)(ii & 7);
+            const unsigned rs_lo = __builtin_amdgcn_perm(rs_pack[1], rs_pack[0], sel), rs_hi = __builtin_amdgcn_perm(rs_pack[3], rs_pack[2], sel);
+            const int slot = done ? 0 : (int)(ii < 8 ? rs_lo : rs_hi) + rank;
+            const unsigned K = (unsigned)(jj * kRowA + 4 * ii) + ((q.s2 >> (b2 + 2)) & 3u);   // the slot word's K (n2: cell_bases' obR & 3)
+            if (!done) {
+                sh.path[P & (kPathMax - 1)][threadIdx.x] = (unsigned short)K;
+                dpath |= ((softTie >> slot) & 1ull) != 0ull ? kDeferPathTie : 0;
+                P += 1;
+            }
+            const int pr = pred_bytes[(slot < kPredLo ? kOffLo : kOffHi) + __mul24(slot, kRowThreads) + (int)threadIdx.x];
+            cw = done ? cw : pr;
+            done = done | (pr == 0xff);
         }
     }
     {
