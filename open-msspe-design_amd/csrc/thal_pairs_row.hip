@@ -382,7 +382,7 @@ static __device__ __forceinline__ void pin_publish64(v32i &Ga, v32i &Wa, v32i &G
 template <int NS>
 static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const ThalConsts &K, const double *gS, const int *gH,
                                                   const SeqPair &q, bool active, unsigned wmax4, int n_slots,
-                                                  bool decisions_only)
+                                                  bool decisions_only, bool edge_values)
 {
     v32i Ga = kRowZero, Wa = kEmptyRowW;   // slot values carry + kRowZero
     typename TabTypes<NS>::B Gb = kRowZero, Wb = kEmptyRowW;
@@ -642,7 +642,31 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
             done = done | (pr == 0xff);
         }
     }
-    {
+    // The picked cell's right end terms (thal.c drawDimer adds them to the path's sums)
+    const KParts pe = k_parts((unsigned)endW >> 17);
+    CellCtx ecc;
+    const CellBases eb = cell_bases(q, pe.ii, pe.jj, ecc);
+    const int rH = sh.h[eb.idxR - kRowGBase];
+    const int N = P - 1;
+    // A call that asks for decisions only does not need the walked structure's sums in Primer3's own order of f64
+    // additions: the DP carries them exactly.  The picked value is pick_g = 2000 (H - 310.15 S) over the path and the
+    // right end, the word's enthalpy field H / 10, hence 620300 S = 20000 h - pick_g as an integer, and
+    //      dG = dH - T (dS + N salt),   dH = 10 h + 200,   dS = S + init_S
+    // follows with two roundings where the reference's sum has a dozen: the two differ by less than 1e-8 cal/mol.
+    // Unless a lane of the wave comes closer to the cut than kCutMargin, the decision is made from that value and the
+    // f64 replay below (a trip per cell of the longest path, table entries from global memory) is skipped.
+    constexpr double kCutMargin = 1e-3;   // cal/mol
+    bool exact = !decisions_only;
+    double Gfast = 0.0;
+    if (decisions_only) {
+        const int ht = word_h(endW) + rH;
+        const double dHf = (double)(ht * 10 + 200);
+        const double dSf = (double)(__mul24(20000, ht) - pick_g) / 620300.0 + K.init_S;
+        Gfast = dHf - (K.temp_k * (dSf + (N * K.salt)));
+        // (an edge record carries its conflict's dG: the reference's own bits)
+        exact = __ballot(!out.r.none && (fabs(Gfast - K.g_cut) < kCutMargin || (edge_values && Gfast <= K.g_cut))) != 0ull;   // wave-uniform
+    }
+    if (exact) {
         int prevCore = 0;
         const int maxP = wave_max_u8(P);
         for (int step_ = 0; step_ < maxP; ++step_) {
@@ -666,23 +690,23 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
                 prevCore = core;
             }
         }
+        // the replayed enthalpy must be the tracked one; anything else is handed on
+        dpath |= (!out.r.none & (H != word_h(endW))) ? kDeferReplay : 0;   // H in units of 10 cal/mol here
+    } else {
+        H = word_h(endW);
     }
-    // the replayed enthalpy must be the tracked one; anything else is handed on
-    dpath |= (!out.r.none & (H != word_h(endW))) ? kDeferReplay : 0;   // H in units of 10 cal/mol here
     // (a path tie is looked at again below: it only changes the number of pairs of the walked structure)
     defer |= dpath & ~kDeferPathTie;
     // ---- thal.c drawDimer(): totals
     {
-        const KParts pe = k_parts((unsigned)endW >> 17);
-        CellCtx cc;
-        const CellBases b = cell_bases(q, pe.ii, pe.jj, cc);
-        const double rS = gS[b.idxR];
-        const int rH = sh.h[b.idxR - kRowGBase];
-        const double dH = (double)((H + rH) * 10 + 200);
-        const double dS = (S + rS) + K.init_S;
-        const int N = P - 1;
-        const double t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
-        const double G = dH - (K.temp_k * (dS + (N * K.salt)));
+        double G = Gfast, t = 0.0;
+        if (exact) {
+            const double rS = gS[eb.idxR];
+            const double dH = (double)((H + rH) * 10 + 200);
+            const double dS = (S + rS) + K.init_S;
+            t = (dH / ((dS + (N * K.salt)) + K.RC)) - kAbsZero;
+            G = dH - (K.temp_k * (dS + (N * K.salt)));
+        }
         if (!out.r.none) {
             out.r.dG = G;
             out.r.t = t;
@@ -789,7 +813,8 @@ static __device__ __forceinline__ void wave_pairs_row(SharedRow &sh, const IntAr
     }
     const unsigned wmax4 = (unsigned)w4[0] | ((unsigned)w4[1] << 8) | ((unsigned)w4[2] << 16) | ((unsigned)w4[3] << 24);
     const bool decisions_only = a.f.sinks.dg == nullptr && a.f.sinks.tm == nullptr;   // wave-uniform
-    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, a.f.ft->H, q, active, wmax4, n_slots, decisions_only);
+    const IntResult r = run_pair_row<NS>(sh, a.f.c, a.f.ft->S, a.f.ft->H, q, active, wmax4, n_slots, decisions_only,
+                                         a.f.sinks.edge_count != nullptr);
     const bool deferred = inside & !spill & (r.defer != 0);
     if (deferred) flag = kNeedsF64;
     spill |= deferred;

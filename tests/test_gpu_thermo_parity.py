@@ -292,6 +292,29 @@ def test_decisions_without_planes_equal_the_exact_planes(eng, m, oracle, oracle_
     np.testing.assert_array_equal(dec[:48], cf.astype(bool))
 
 
+@pytest.mark.parametrize("k", [13, 15])
+def test_decisions_at_cuts_that_are_pairs_own_values(eng, m, k):
+    """A decisions-only call takes a pair's dG from the sums the integer DP carries (two roundings) and replays the
+    structure in the reference's own order of f64 additions only when a lane of the wave comes within 1e-3 cal/mol
+    of the cut (thal_pairs_row.hip kCutMargin).  Thresholds that ARE the dG of pairs of the pool, as the f32 the
+    reference compares in, put pairs exactly there: every decision must still be the exact plane's."""
+    n = 1536
+    pool = m.synth.pool_strings(m.synth.random_pool(n, k, seed=77 + k))
+    chem = m.Chem.ntthal()
+    exact = eng.cross_dimer(pool, chem, -9000.0, want_dg=True)
+    dg = exact["dg"]
+    finite = np.sort(dg[np.isfinite(dg)])
+    near = 0
+    for q in (0.002, 0.01, 0.05, 0.2, 0.5):
+        thr = float(np.float32(finite[int(q * finite.size)]))
+        cut = m.g_cut(thr)
+        near += int((np.abs(dg - cut) < 1e-3).sum())
+        fast = eng.cross_dimer(pool, chem, thr, want_dg=False, want_tm=False)
+        np.testing.assert_array_equal(bitmap_to_bool(fast["bitmap"], n), dg <= cut)
+        np.testing.assert_array_equal(fast["row_conflicts"], (dg <= cut).sum(1).astype(np.uint32))
+    assert near > 0      # pairs sat inside the margin
+
+
 @pytest.mark.parametrize("k,pair_kernel", [(9, "auto"), (13, "auto"), (13, "int"), (13, "f64"), (15, "auto")])
 def test_pairs_without_a_complementary_cell(eng, m, oracle, oracle_tables, k, pair_kernel):
     """Two-letter pools (T/C against T/C, A/G against A/G): whole waves in which no pair has a single
