@@ -87,8 +87,9 @@ with open(OUT / f"{ROUND}_pmc_{KERNEL}.txt", "w") as f:
     f.write(f"wave cycles: active / issue-stalled / waiting   {c2['SQ_ACTIVE_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / "
             f"{c1['SQ_WAIT_INST_ANY'] / c1['SQ_WAVE_CYCLES']:.3f} / {c1['SQ_WAIT_ANY'] / c1['SQ_WAVE_CYCLES']:.3f}\n")
     f.write(f"LDS bank-conflict share of LDS active       {c2['SQ_LDS_BANK_CONFLICT'] / c2['SQ_LDS_IDX_ACTIVE']:.3f}\n")
-    f.write(f"VALU busy share of SIMD cycles              {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}   (SQ_ACTIVE_INST_VALU quad-cycles "
-            f"= SQ_INSTS_VALU x {c2['SQ_ACTIVE_INST_VALU'] / c1['SQ_INSTS_VALU']:.3f}: every VALU instruction holds its SIMD for one quad-cycle, whatever its class)\n")
+    f.write(f"SQ_ACTIVE_INST_VALU x 4 / SIMD cycles         {c2['SQ_ACTIVE_INST_VALU'] / simd_quads:.3f}   (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU x "
+            f"{c2['SQ_ACTIVE_INST_VALU'] / c1['SQ_INSTS_VALU']:.3f}: on gfx950 the counter repeats the instruction count -- a value above 1 here "
+            f"means more 'busy quad-cycles' than the launch has -- so it is NOT a busy-time measure; the figure to read is cycles per instruction above)\n")
 hbm = 2.0 * cf["FETCH_SIZE"] * 1024.0 + cw["WRITE_SIZE"] * 1024.0
 (OUT / "traffic_latest.json").write_text(json.dumps({
     "kernel": KERNEL, "round": int(ROUND[1:]), "commit": COMMIT,
