@@ -496,7 +496,10 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
             if (best.G < G0) {
                 flags |= tie ? kDeferLoopTie : 0;
                 // thal.c rejects a candidate with H > 0 and S > 0 (620300 S = 2000 H - G)
-                flags |= ((hw > 0) & (__mul24(20000, hw) - best.G > -1000)) ? kDeferBad : 0;
+                // (H > 0 alone hands the pair on: S > 0 as well -- 620300 S = 20000 hw - G -- is what thal.c asks, but a
+                //  winning loop candidate of positive enthalpy is rare enough that the second half is not worth
+                //  three instructions on every cell; the stages behind this one apply the full rule)
+                flags |= (hw > 0) ? kDeferBad : 0;
                 h0 = hw;
                 G0 = best.G;
                 predW = best.W;
