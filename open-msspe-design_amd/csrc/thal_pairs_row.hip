@@ -489,10 +489,13 @@ static __device__ __forceinline__ IntResult run_pair_row(SharedRow &sh, const Th
         // ---- loops (thal.c calc_bulge_internal acceptance: dG of the candidate strictly lower)
         if (best.G <= G0) {
             // exact enthalpy of the best candidate: the loop term's from the table that mirrors T
-            const unsigned idx = row_index(rc.C, (unsigned)best.W);
-            const int th = sh.TH[idx >> 2];
-            const int hw = (th >> 1) + ((th & 1) ? sh.ytsh[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)] : 0) +
-                           word_h(best.W);
+            // (TH's entry of table byte address A is the short at byte A / 2: one shift, the clamp in the halved domain --
+            //  floor commutes with min -- and the cell-side enthalpy read beside it, unconditionally, then multiplied by
+            //  the entry's flag: one LDS round trip and no exec juggling)
+            const unsigned th_at = min((rc.C - (unsigned)best.W) >> 16, (unsigned)kRowTBytes >> 1) & ~1u;
+            const int th = *reinterpret_cast<const short *>(reinterpret_cast<const char *>(sh.TH) + th_at);
+            const int ysh = sh.ytsh[(im1 << 2) | (int)(((q.s2 << 2) >> (2 * jm1)) & 3u)];
+            const int hw = (th >> 1) + __mul24(th & 1, ysh) + word_h(best.W);
             if (best.G < G0) {
                 flags |= tie ? kDeferLoopTie : 0;
                 // thal.c rejects a candidate with H > 0 and S > 0 (620300 S = 2000 H - G)
