@@ -176,7 +176,9 @@ int msspe_last_overflow_pairs(msspe_ctx *ctx, uint64_t *count_out);
  * answer because Primer3's double comparisons could go either way (they are retried in list
  * mode), out[1..7] = how many of them met each reason (Tm near-tie, loop == stack/start value with
  * another enthalpy, tie between loops, rejected minimum, tie in the terminal pick, replay
- * mismatch, equal-valued alternative on the optimal path).  out[8..15]: the same for the list-mode
+ * mismatch, equal-valued alternative on the optimal path; the row-specialised matrix kernel counts every
+ * winning loop candidate of positive enthalpy as a rejected minimum and leaves the entropy half of thal.c's
+ * rule to the list mode).  out[8..15]: the same for the list-mode
  * kernel; out[8] is the number of pairs that needed the f64 kernels.  Reading resets the counters. */
 int msspe_pair_stage_stats(msspe_ctx *ctx, uint64_t out[16]);
 /* Up to 1024 of those pairs (call before msspe_pair_stage_stats, which resets the sample count):
